@@ -1,0 +1,208 @@
+"""ctypes binding of libsvgf_hip.so (include/svgf.h) and a host-side mirror of the reference interface.
+
+The reference's interface for this path is three free functions over global state
+(reference src/denoise.h:6-8): denoiseInit(scene) / denoise(out, in, gbuffer) / denoiseFree(), with the tunables
+in `ui_*` globals (src/main.h:39-69).  `Denoiser` keeps those names and meanings:
+    d = Denoiser(width, height, device=0)     # denoiseInit
+    d.ui.temporal_enable = 1 ...              # the ui_* block
+    d.denoise(out, inp, gbuffer, camera)      # denoise (device pointers / torch tensors)
+    d.free()                                  # denoiseFree
+There is NO CPU fallback: if the HIP library is missing or no GPU is present, construction raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsvgf_hip.so")
+
+SVGF_OK = 0
+STATE_HISTORY_LENGTH, STATE_MOMENTS, STATE_COLOR_HISTORY, STATE_VARIANCE_TEMPORAL, STATE_COLOR_ACC = range(5)
+KERNEL_TEMPORAL, KERNEL_PREPARE, KERNEL_ATROUS, KERNEL_DEBUGVIEW, KERNEL_COPYOUT = 1, 2, 3, 4, 5
+MAX_LEVELS = 10
+
+# every symbol include/svgf.h declares
+EXPORTS = ["svgf_version", "svgf_params_default", "svgf_create", "svgf_destroy", "svgf_reset", "svgf_denoise",
+           "svgf_denoise_host", "svgf_sync", "svgf_last_error", "svgf_width", "svgf_height", "svgf_read_state",
+           "svgf_set_capture", "svgf_profile_enable", "svgf_profile_frames", "svgf_profile_read"]
+
+
+class SvgfCamera(C.Structure):
+    _fields_ = [("right", C.c_float * 3), ("up", C.c_float * 3), ("view", C.c_float * 3), ("position", C.c_float * 3)]
+
+    @classmethod
+    def from_dict(cls, d):
+        c = cls()
+        for k in ("right", "up", "view", "position"):
+            for i in range(3):
+                getattr(c, k)[i] = float(d[k][i])
+        return c
+
+
+class SvgfParams(C.Structure):
+    _fields_ = [("temporal_enable", C.c_int), ("spatial_enable", C.c_int), ("color_alpha", C.c_float),
+                ("moment_alpha", C.c_float), ("blur_variance", C.c_int), ("sigma_l", C.c_float),
+                ("sigma_x", C.c_float), ("sigma_n", C.c_float), ("atrous_nlevel", C.c_int),
+                ("history_level", C.c_int), ("sepcolor", C.c_int), ("addcolor", C.c_int),
+                ("right_view_option", C.c_int), ("kernel_variant", C.c_int), ("reserved", C.c_int * 3)]
+
+    def set(self, **kw):
+        for k, v in kw.items():
+            if not hasattr(self, k):
+                raise AttributeError(k)
+            setattr(self, k, v)
+        return self
+
+
+def reference_defaults() -> SvgfParams:
+    """ui_* defaults of reference src/main.cpp:49-62 (pure Python copy; the library's svgf_params_default is
+    checked against this in tests)."""
+    p = SvgfParams()
+    p.set(temporal_enable=0, spatial_enable=0, color_alpha=0.2, moment_alpha=0.2, blur_variance=1, sigma_l=0.45,
+          sigma_x=0.35, sigma_n=0.2, atrous_nlevel=5, history_level=1, sepcolor=0, addcolor=0, right_view_option=0)
+    return p
+
+
+class SvgfError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load_library(path: str | None = None):
+    """Load libsvgf_hip.so and declare prototypes.  Fails loudly when the library is absent."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    path = path or LIB_PATH
+    if not os.path.exists(path):
+        raise SvgfError(f"{path} not found: build it first (python -c 'import __graft_entry__ as g; g.build()'). "
+                        "There is no CPU fallback.")
+    lib = C.CDLL(path)
+    vp, ip = C.c_void_p, C.c_int
+    lib.svgf_version.restype = ip
+    lib.svgf_params_default.argtypes = [C.POINTER(SvgfParams)]
+    lib.svgf_create.argtypes = [ip, ip, ip, C.POINTER(vp)]
+    lib.svgf_destroy.argtypes = [vp]
+    lib.svgf_reset.argtypes = [vp]
+    lib.svgf_denoise.argtypes = [vp, vp, vp, vp, C.POINTER(SvgfCamera), C.POINTER(SvgfParams), vp]
+    lib.svgf_denoise_host.argtypes = [vp, vp, vp, vp, C.POINTER(SvgfCamera), C.POINTER(SvgfParams)]
+    lib.svgf_sync.argtypes = [vp]
+    lib.svgf_last_error.argtypes = [vp]
+    lib.svgf_last_error.restype = C.c_char_p
+    lib.svgf_width.argtypes = [vp]
+    lib.svgf_height.argtypes = [vp]
+    lib.svgf_read_state.argtypes = [vp, ip, vp, C.c_ulonglong]
+    lib.svgf_set_capture.argtypes = [vp, ip]
+    lib.svgf_profile_enable.argtypes = [vp, ip]
+    lib.svgf_profile_frames.argtypes = [vp]
+    lib.svgf_profile_frames.restype = C.c_longlong
+    lib.svgf_profile_read.argtypes = [vp, ip, ip, C.POINTER(ip), C.POINTER(C.c_float), C.POINTER(ip)]
+    if path == LIB_PATH:
+        _lib = lib
+    return lib
+
+
+def _ptr(x):
+    """device pointer of a torch tensor / int / None"""
+    if x is None:
+        return None
+    if isinstance(x, int):
+        return x
+    if hasattr(x, "data_ptr"):
+        if not x.is_contiguous():
+            raise SvgfError("tensor must be contiguous")
+        return x.data_ptr()
+    raise TypeError(type(x))
+
+
+class Denoiser:
+    """One SVGF context on one GPU (denoiseInit .. denoiseFree of the reference, handle-based)."""
+
+    def __init__(self, width: int, height: int, device: int = 0):
+        self.lib = load_library()
+        self.width, self.height = int(width), int(height)
+        self.ui = SvgfParams()
+        self.lib.svgf_params_default(C.byref(self.ui))
+        h = C.c_void_p()
+        rc = self.lib.svgf_create(int(device), self.width, self.height, C.byref(h))
+        if rc != SVGF_OK:
+            raise SvgfError(f"svgf_create({device},{width},{height}) -> {rc}: {self.lib.svgf_last_error(None).decode()}")
+        self.h = h
+
+    def _check(self, rc, what):
+        if rc != SVGF_OK:
+            raise SvgfError(f"{what} -> {rc}: {self.lib.svgf_last_error(self.h).decode()}")
+
+    # --- reference-named lifecycle ---
+    def free(self):
+        if getattr(self, "h", None):
+            self.lib.svgf_destroy(self.h)
+            self.h = None
+
+    denoiseFree = free
+
+    def reset(self):
+        self._check(self.lib.svgf_reset(self.h), "svgf_reset")
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+    def denoise(self, out, inp, gbuffer, camera, params: SvgfParams | None = None, stream=None):
+        """Device pointers (ints) or contiguous CUDA torch tensors.  Asynchronous on `stream`."""
+        cam = camera if isinstance(camera, SvgfCamera) else SvgfCamera.from_dict(camera)
+        p = params if params is not None else self.ui
+        s = None if stream is None else (stream if isinstance(stream, int) else stream.cuda_stream)
+        self._check(self.lib.svgf_denoise(self.h, _ptr(out), _ptr(inp), _ptr(gbuffer), C.byref(cam), C.byref(p), s),
+                    "svgf_denoise")
+
+    def denoise_host(self, color: np.ndarray, gbuffer: np.ndarray, camera, params: SvgfParams | None = None) -> np.ndarray:
+        """numpy in, numpy out (uploads, runs, downloads, synchronises)."""
+        color = np.ascontiguousarray(color, dtype=np.float32)
+        gbuffer = np.ascontiguousarray(gbuffer)
+        assert color.size == 3 * self.width * self.height and gbuffer.nbytes == 52 * self.width * self.height
+        out = np.empty_like(color)
+        cam = camera if isinstance(camera, SvgfCamera) else SvgfCamera.from_dict(camera)
+        p = params if params is not None else self.ui
+        self._check(self.lib.svgf_denoise_host(self.h, out.ctypes.data, color.ctypes.data, gbuffer.ctypes.data,
+                                               C.byref(cam), C.byref(p)), "svgf_denoise_host")
+        return out
+
+    def sync(self):
+        self._check(self.lib.svgf_sync(self.h), "svgf_sync")
+
+    def set_capture(self, on: bool = True):
+        self._check(self.lib.svgf_set_capture(self.h, 1 if on else 0), "svgf_set_capture")
+
+    def read_state(self, which: int) -> np.ndarray:
+        n = self.width * self.height
+        shape, dt = {STATE_HISTORY_LENGTH: ((self.height, self.width), np.int32),
+                     STATE_MOMENTS: ((self.height, self.width, 2), np.float32),
+                     STATE_COLOR_HISTORY: ((self.height, self.width, 3), np.float32),
+                     STATE_VARIANCE_TEMPORAL: ((self.height, self.width), np.float32),
+                     STATE_COLOR_ACC: ((self.height, self.width, 3), np.float32)}[which]
+        a = np.empty(shape, dtype=dt)
+        assert a.size >= n
+        self._check(self.lib.svgf_read_state(self.h, which, a.ctypes.data, a.nbytes), "svgf_read_state")
+        return a
+
+    # --- profiling ---
+    def profile_enable(self, nframes: int):
+        self._check(self.lib.svgf_profile_enable(self.h, int(nframes)), "svgf_profile_enable")
+
+    def profile_frames(self) -> int:
+        return int(self.lib.svgf_profile_frames(self.h))
+
+    def profile_read(self, slot: int):
+        kinds = (C.c_int * 32)()
+        ms = (C.c_float * 32)()
+        n = C.c_int()
+        self._check(self.lib.svgf_profile_read(self.h, slot, 32, kinds, ms, C.byref(n)), "svgf_profile_read")
+        return [(kinds[i], ms[i]) for i in range(n.value)]

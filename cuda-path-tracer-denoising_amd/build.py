@@ -1,0 +1,71 @@
+"""Build recipes (no cmake, no JIT cache): everything lands in-tree so it travels to the GPU box."""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(_HERE)
+CSRC = os.path.join(_HERE, "csrc")
+LIB = os.path.join(_HERE, "libsvgf_hip.so")
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+ORACLE_LIB = os.path.join(ORACLE_DIR, "libsvgf_oracle.so")
+
+HIP_SOURCES = ["svgf_api.hip", "svgf_kernels.hip", "svgf_atrous_strip.hip"]
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-function"]
+
+
+def _newer(target: str, deps: list[str]) -> bool:
+    if not os.path.exists(target):
+        return False
+    t = os.path.getmtime(target)
+    return all(os.path.getmtime(d) <= t for d in deps)
+
+
+def _run(cmd: list[str], cwd: str | None = None):
+    r = subprocess.run(cmd, cwd=cwd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("build failed: " + " ".join(cmd) + "\n" + r.stdout)
+    return r.stdout
+
+
+def hipcc_path() -> str:
+    p = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(p):
+        raise RuntimeError("hipcc not found")
+    return p
+
+
+def build_hip(force: bool = False) -> str:
+    """Compile the HIP kernels + C ABI for gfx950 into cuda-path-tracer-denoising_amd/libsvgf_hip.so."""
+    srcs = [os.path.join(CSRC, s) for s in HIP_SOURCES]
+    deps = srcs + [os.path.join(CSRC, "svgf_kernels.h"), os.path.join(ROOT, "include", "svgf.h")]
+    if not force and _newer(LIB, deps):
+        return LIB
+    _run([hipcc_path()] + HIPCC_FLAGS + srcs + ["-o", LIB])
+    return LIB
+
+
+def build_oracle(force: bool = False) -> str:
+    """Compile the CPU oracle (test infrastructure) into oracle/libsvgf_oracle.so."""
+    src = os.path.join(ORACLE_DIR, "svgf_oracle.c")
+    deps = [src, os.path.join(ORACLE_DIR, "svgf_oracle.h"), os.path.join(ROOT, "include", "svgf.h")]
+    if not force and _newer(ORACLE_LIB, deps):
+        return ORACLE_LIB
+    _run(["gcc", "-O2", "-ffp-contract=off", "-fopenmp", "-shared", "-fPIC", "-std=c11", "-Wall", src, "-o", ORACLE_LIB, "-lm"])
+    return ORACLE_LIB
+
+
+def build_reference(force: bool = False) -> str | None:
+    """Build the reference's own denoise.cu for gfx950 into oracle/_ref/ (only where /root/reference exists)."""
+    if not os.path.isdir("/root/reference/src"):
+        return None
+    out = os.path.join(ORACLE_DIR, "_ref", "ref_denoise_gpu")
+    mk = os.path.join(ORACLE_DIR, "ref", "Makefile")
+    if not os.path.exists(mk):
+        return None
+    if force and os.path.exists(out):
+        os.remove(out)
+    _run(["make", "-s", "-C", os.path.join(ORACLE_DIR, "ref")])
+    return out if os.path.exists(out) else None

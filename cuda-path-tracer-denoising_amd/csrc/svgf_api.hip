@@ -1,0 +1,465 @@
+// svgf_api.hip — host side of libsvgf_hip.so: context, history rotation, per-frame kernel sequence, C ABI.
+//
+// Mirrors the host sequence of reference denoise() (src/denoise.cu:349-402) with two structural changes that
+// do not alter results:
+//   * no device-to-device copies: the five per-frame cudaMemcpy's (src/denoise.cu:366,391,396-398) become
+//     index rotation over ping-pong planes;
+//   * variance is never updated in place: each a-trous level reads {colour,variance} plane A and writes plane B,
+//     which is the "snapshot" semantics the parity contract fixes (SURVEY.md §7 hard parts, §8c).
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+
+#include "../../include/svgf.h"
+#include "svgf_kernels.h"
+
+#define SVGF_MAX_KERNELS_PER_FRAME (SVGF_MAX_LEVELS + 4)
+
+struct svgf_ctx {
+    int device, W, H;
+    size_t n;
+    float4 *cv[3];
+    float *nrm[2];
+    int *gid[2];
+    float *pos;
+    float2 *mom[2];
+    int *hlen[2];
+    int hist;      // cv index holding the colour history
+    int acc;       // cv index the last temporal pass wrote
+    int cur;       // mom/hlen index holding the history the next frame reads
+    int gcur;      // nrm/gid index holding the previous frame's planes
+    float view_prev[16];   // column-major; identity until the first frame (reference src/denoise.cu:15)
+    // state capture for tests
+    int capture;
+    float4 *cv_capture;
+    // staging for svgf_denoise_host
+    float *st_in, *st_out; void *st_g;
+    // profiling
+    int prof_frames;       // 0 = off
+    long long prof_count;  // frames recorded since enable
+    hipEvent_t *ev;        // prof_frames * SVGF_MAX_KERNELS_PER_FRAME * 2
+    int *ev_kind;          // prof_frames * SVGF_MAX_KERNELS_PER_FRAME
+    int *ev_n;             // prof_frames
+    char err[512];
+};
+
+static char g_create_err[512] = "";
+
+#define HIPC(ctx, call)                                                                              \
+    do {                                                                                             \
+        hipError_t e__ = (call);                                                                     \
+        if (e__ != hipSuccess) {                                                                     \
+            snprintf((ctx)->err, sizeof((ctx)->err), "%s failed: %s (%s:%d)", #call,                 \
+                     hipGetErrorString(e__), __FILE__, __LINE__);                                    \
+            return SVGF_ERR_HIP;                                                                     \
+        }                                                                                            \
+    } while (0)
+
+// ---- host copy of the view-matrix construction (reference GetViewMatrix src/denoise.cu:342-347) -------------
+// inverse of the column-major matrix [right|0, up|0, view|0, position|1] by 2x2-minor (cofactor) expansion in the
+// operation order of glm 0.9.6.3 (external/include/glm/detail/type_mat4x4.inl:37-92), so fp32 rounding matches.
+static void view_matrix_from_camera(const SvgfCamera *cam, float *out)
+{
+    float m[16];
+    for (int r = 0; r < 3; r++) {
+        m[0 + r] = cam->right[r]; m[4 + r] = cam->up[r]; m[8 + r] = cam->view[r]; m[12 + r] = cam->position[r];
+    }
+    m[3] = m[7] = m[11] = 0.0f; m[15] = 1.0f;
+    auto M = [&](int c, int r) { return m[c * 4 + r]; };
+    float fac[6][4];
+    const int rows[6][2] = { {2, 3}, {1, 3}, {1, 2}, {0, 3}, {0, 2}, {0, 1} };
+    for (int k = 0; k < 6; k++) {
+        const int ra = rows[k][0], rb = rows[k][1];
+        const float a = M(2, ra) * M(3, rb) - M(3, ra) * M(2, rb);
+        const float b = M(1, ra) * M(3, rb) - M(3, ra) * M(1, rb);
+        const float c = M(1, ra) * M(2, rb) - M(2, ra) * M(1, rb);
+        fac[k][0] = a; fac[k][1] = a; fac[k][2] = b; fac[k][3] = c;
+    }
+    float vec[4][4];
+    for (int r = 0; r < 4; r++) { vec[r][0] = M(1, r); vec[r][1] = vec[r][2] = vec[r][3] = M(0, r); }
+    const int comb[4][6] = { {1, 0, 2, 1, 3, 2}, {0, 0, 2, 3, 3, 4}, {0, 1, 1, 3, 3, 5}, {0, 2, 1, 4, 2, 5} };
+    float inv[16];
+    for (int c = 0; c < 4; c++)
+        for (int r = 0; r < 4; r++) {
+            float t = vec[comb[c][0]][r] * fac[comb[c][1]][r] - vec[comb[c][2]][r] * fac[comb[c][3]][r];
+            t = t + vec[comb[c][4]][r] * fac[comb[c][5]][r];
+            inv[c * 4 + r] = ((c + r) & 1) ? t * -1.0f : t * 1.0f;
+        }
+    const float d0 = m[0] * inv[0], d1 = m[1] * inv[4], d2 = m[2] * inv[8], d3 = m[3] * inv[12];
+    const float det = (d0 + d1) + (d2 + d3);
+    const float rdet = 1.0f / det;
+    for (int k = 0; k < 16; k++) out[k] = inv[k] * rdet;
+}
+
+extern "C" int svgf_version(void) { return (SVGF_VERSION_MAJOR << 16) | SVGF_VERSION_MINOR; }
+
+extern "C" int svgf_params_default(SvgfParams *p)
+{
+    if (!p) return SVGF_ERR_INVALID_ARG;
+    memset(p, 0, sizeof(*p));
+    p->temporal_enable = 0; p->spatial_enable = 0;            // reference src/main.cpp:50-52
+    p->color_alpha = 0.2f; p->moment_alpha = 0.2f;            // :53-54
+    p->blur_variance = 1;                                     // :55
+    p->sigma_l = 0.45f; p->sigma_x = 0.35f; p->sigma_n = 0.2f; // :56-58
+    p->atrous_nlevel = 5; p->history_level = 1;               // :59-60
+    p->sepcolor = 0; p->addcolor = 0; p->right_view_option = 0;
+    return SVGF_OK;
+}
+
+static void free_all(svgf_ctx *c)
+{
+    for (int k = 0; k < 3; k++) if (c->cv[k]) (void)hipFree(c->cv[k]);
+    for (int k = 0; k < 2; k++) {
+        if (c->nrm[k]) (void)hipFree(c->nrm[k]);
+        if (c->gid[k]) (void)hipFree(c->gid[k]);
+        if (c->mom[k]) (void)hipFree(c->mom[k]);
+        if (c->hlen[k]) (void)hipFree(c->hlen[k]);
+    }
+    if (c->pos) (void)hipFree(c->pos);
+    if (c->cv_capture) (void)hipFree(c->cv_capture);
+    if (c->st_in) (void)hipFree(c->st_in);
+    if (c->st_out) (void)hipFree(c->st_out);
+    if (c->st_g) (void)hipFree(c->st_g);
+    if (c->ev) {
+        for (long long k = 0; k < (long long)c->prof_frames * SVGF_MAX_KERNELS_PER_FRAME * 2; k++) (void)hipEventDestroy(c->ev[k]);
+        free(c->ev); free(c->ev_kind); free(c->ev_n);
+    }
+}
+
+static int zero_state(svgf_ctx *c)
+{
+    for (int k = 0; k < 3; k++) HIPC(c, hipMemset(c->cv[k], 0, c->n * sizeof(float4)));
+    for (int k = 0; k < 2; k++) {
+        HIPC(c, hipMemset(c->nrm[k], 0, c->n * 3 * sizeof(float)));
+        HIPC(c, hipMemset(c->gid[k], 0, c->n * sizeof(int)));
+        HIPC(c, hipMemset(c->mom[k], 0, c->n * sizeof(float2)));
+        HIPC(c, hipMemset(c->hlen[k], 0, c->n * sizeof(int)));
+    }
+    HIPC(c, hipMemset(c->pos, 0, c->n * 3 * sizeof(float)));
+    c->hist = 0; c->acc = 0; c->cur = 0; c->gcur = 0;
+    return SVGF_OK;
+}
+
+extern "C" int svgf_create(int device, int width, int height, svgf_ctx **out)
+{
+    if (!out) return SVGF_ERR_INVALID_ARG;
+    *out = nullptr;
+    if (width <= 0 || height <= 0 || (long long)width * height > (1LL << 30)) {
+        snprintf(g_create_err, sizeof(g_create_err), "svgf_create: bad size %dx%d", width, height);
+        return SVGF_ERR_INVALID_ARG;
+    }
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) {
+        snprintf(g_create_err, sizeof(g_create_err), "svgf_create: no usable HIP device %d (count %d, %s)", device,
+                 ndev, hipGetErrorString(e));
+        return SVGF_ERR_NO_DEVICE;
+    }
+    if ((e = hipSetDevice(device)) != hipSuccess) {
+        snprintf(g_create_err, sizeof(g_create_err), "hipSetDevice(%d): %s", device, hipGetErrorString(e));
+        return SVGF_ERR_NO_DEVICE;
+    }
+    svgf_ctx *c = new (std::nothrow) svgf_ctx();
+    if (!c) return SVGF_ERR_OOM;
+    memset(c, 0, sizeof(*c));
+    c->device = device; c->W = width; c->H = height; c->n = (size_t)width * height;
+    for (int k = 0; k < 16; k++) c->view_prev[k] = (k % 5 == 0) ? 1.0f : 0.0f;
+    bool ok = true;
+    for (int k = 0; k < 3 && ok; k++) ok = hipMalloc((void **)&c->cv[k], c->n * sizeof(float4)) == hipSuccess;
+    for (int k = 0; k < 2 && ok; k++) {
+        ok = ok && hipMalloc((void **)&c->nrm[k], c->n * 3 * sizeof(float)) == hipSuccess;
+        ok = ok && hipMalloc((void **)&c->gid[k], c->n * sizeof(int)) == hipSuccess;
+        ok = ok && hipMalloc((void **)&c->mom[k], c->n * sizeof(float2)) == hipSuccess;
+        ok = ok && hipMalloc((void **)&c->hlen[k], c->n * sizeof(int)) == hipSuccess;
+    }
+    ok = ok && hipMalloc((void **)&c->pos, c->n * 3 * sizeof(float)) == hipSuccess;
+    if (!ok) {
+        snprintf(g_create_err, sizeof(g_create_err), "svgf_create: hipMalloc failed for %dx%d", width, height);
+        free_all(c); delete c;
+        return SVGF_ERR_OOM;
+    }
+    if (zero_state(c) != SVGF_OK) {
+        snprintf(g_create_err, sizeof(g_create_err), "%s", c->err);
+        free_all(c); delete c;
+        return SVGF_ERR_HIP;
+    }
+    *out = c;
+    return SVGF_OK;
+}
+
+extern "C" int svgf_destroy(svgf_ctx *c)
+{
+    if (!c) return SVGF_OK;
+    (void)hipSetDevice(c->device);
+    (void)hipDeviceSynchronize();
+    free_all(c);
+    delete c;
+    return SVGF_OK;
+}
+
+extern "C" int svgf_reset(svgf_ctx *c)
+{
+    if (!c) return SVGF_ERR_INVALID_ARG;
+    HIPC(c, hipSetDevice(c->device));
+    HIPC(c, hipDeviceSynchronize());
+    return zero_state(c);
+}
+
+extern "C" int svgf_sync(svgf_ctx *c)
+{
+    if (!c) return SVGF_ERR_INVALID_ARG;
+    HIPC(c, hipSetDevice(c->device));
+    HIPC(c, hipDeviceSynchronize());
+    return SVGF_OK;
+}
+
+extern "C" const char *svgf_last_error(const svgf_ctx *c) { return c ? c->err : g_create_err; }
+extern "C" int svgf_width(const svgf_ctx *c) { return c ? c->W : 0; }
+extern "C" int svgf_height(const svgf_ctx *c) { return c ? c->H : 0; }
+
+extern "C" int svgf_set_capture(svgf_ctx *c, int on)
+{
+    if (!c) return SVGF_ERR_INVALID_ARG;
+    HIPC(c, hipSetDevice(c->device));
+    if (on && !c->cv_capture) {
+        HIPC(c, hipMalloc((void **)&c->cv_capture, c->n * sizeof(float4)));
+        HIPC(c, hipMemset(c->cv_capture, 0, c->n * sizeof(float4)));
+    }
+    c->capture = on ? 1 : 0;
+    return SVGF_OK;
+}
+
+// ---- profiling ---------------------------------------------------------------------------------------------
+
+extern "C" int svgf_profile_enable(svgf_ctx *c, int nframes)
+{
+    if (!c || nframes < 0) return SVGF_ERR_INVALID_ARG;
+    HIPC(c, hipSetDevice(c->device));
+    if (c->ev) {
+        for (long long k = 0; k < (long long)c->prof_frames * SVGF_MAX_KERNELS_PER_FRAME * 2; k++) (void)hipEventDestroy(c->ev[k]);
+        free(c->ev); free(c->ev_kind); free(c->ev_n);
+        c->ev = nullptr; c->ev_kind = nullptr; c->ev_n = nullptr;
+    }
+    c->prof_frames = 0; c->prof_count = 0;
+    if (nframes == 0) return SVGF_OK;
+    const long long ne = (long long)nframes * SVGF_MAX_KERNELS_PER_FRAME * 2;
+    c->ev = (hipEvent_t *)calloc(ne, sizeof(hipEvent_t));
+    c->ev_kind = (int *)calloc((size_t)nframes * SVGF_MAX_KERNELS_PER_FRAME, sizeof(int));
+    c->ev_n = (int *)calloc(nframes, sizeof(int));
+    if (!c->ev || !c->ev_kind || !c->ev_n) return SVGF_ERR_OOM;
+    for (long long k = 0; k < ne; k++) HIPC(c, hipEventCreate(&c->ev[k]));
+    c->prof_frames = nframes;
+    return SVGF_OK;
+}
+
+extern "C" long long svgf_profile_frames(const svgf_ctx *c) { return c ? c->prof_count : 0; }
+
+extern "C" int svgf_profile_read(svgf_ctx *c, int slot, int max_entries, int *kinds, float *ms, int *n_out)
+{
+    if (!c || !n_out || slot < 0 || slot >= c->prof_frames) return SVGF_ERR_INVALID_ARG;
+    HIPC(c, hipSetDevice(c->device));
+    const int nk = c->ev_n[slot];
+    int w = 0;
+    for (int k = 0; k < nk && w < max_entries; k++, w++) {
+        const long long base = ((long long)slot * SVGF_MAX_KERNELS_PER_FRAME + k) * 2;
+        float t = 0.0f;
+        HIPC(c, hipEventElapsedTime(&t, c->ev[base], c->ev[base + 1]));
+        if (kinds) kinds[w] = c->ev_kind[slot * SVGF_MAX_KERNELS_PER_FRAME + k];
+        if (ms) ms[w] = t;
+    }
+    *n_out = w;
+    return SVGF_OK;
+}
+
+namespace {
+struct KernelTimer {   // brackets one launch with an event pair when profiling is on
+    svgf_ctx *c; hipStream_t s; int slot; int k;
+    bool begin(int kind) {
+        if (!c->prof_frames) return true;
+        k = c->ev_n[slot];
+        if (k >= SVGF_MAX_KERNELS_PER_FRAME) return true;
+        c->ev_kind[slot * SVGF_MAX_KERNELS_PER_FRAME + k] = kind;
+        return hipEventRecord(c->ev[((long long)slot * SVGF_MAX_KERNELS_PER_FRAME + k) * 2], s) == hipSuccess;
+    }
+    bool end() {
+        if (!c->prof_frames || k >= SVGF_MAX_KERNELS_PER_FRAME) return true;
+        c->ev_n[slot] = k + 1;
+        return hipEventRecord(c->ev[((long long)slot * SVGF_MAX_KERNELS_PER_FRAME + k) * 2 + 1], s) == hipSuccess;
+    }
+};
+}  // namespace
+
+#define LAUNCH(kind, expr)                                                                           \
+    do {                                                                                             \
+        if (!timer.begin(kind)) { snprintf(c->err, sizeof(c->err), "hipEventRecord failed"); return SVGF_ERR_HIP; } \
+        HIPC(c, (expr));                                                                             \
+        if (!timer.end()) { snprintf(c->err, sizeof(c->err), "hipEventRecord failed"); return SVGF_ERR_HIP; }       \
+    } while (0)
+
+// ---- the frame ------------------------------------------------------------------------------------------------
+
+extern "C" int svgf_denoise(svgf_ctx *c, void *out_rgb_dev, const void *in_rgb_dev, const void *gbuffer_dev,
+                            const SvgfCamera *cam, const SvgfParams *p, void *stream)
+{
+    if (!c) return SVGF_ERR_INVALID_ARG;
+    if (!out_rgb_dev || !in_rgb_dev || !gbuffer_dev || !cam || !p) {
+        snprintf(c->err, sizeof(c->err), "svgf_denoise: null argument");
+        return SVGF_ERR_INVALID_ARG;
+    }
+    if (p->atrous_nlevel < 0 || p->atrous_nlevel > SVGF_MAX_LEVELS) {
+        snprintf(c->err, sizeof(c->err), "svgf_denoise: atrous_nlevel %d outside 0..%d", p->atrous_nlevel, SVGF_MAX_LEVELS);
+        return SVGF_ERR_INVALID_ARG;
+    }
+    if (p->kernel_variant < 0 || p->kernel_variant > 2) {
+        snprintf(c->err, sizeof(c->err), "svgf_denoise: kernel_variant %d unknown", p->kernel_variant);
+        return SVGF_ERR_INVALID_ARG;
+    }
+    HIPC(c, hipSetDevice(c->device));
+    hipStream_t s = (hipStream_t)stream;
+    float *out = (float *)out_rgb_dev;
+    const float *in = (const float *)in_rgb_dev;
+    const float *g = (const float *)gbuffer_dev;
+    const int n = (int)c->n;
+
+    KernelTimer timer{ c, s, 0, 0 };
+    if (c->prof_frames) {
+        timer.slot = (int)(c->prof_count % c->prof_frames);
+        c->ev_n[timer.slot] = 0;
+    }
+
+    // 1) temporal accumulation, or constant variance (reference :360-371).  Writes the cv plane `acc` (never the
+    //    one holding the colour history) and the current-frame G-buffer planes.
+    const int acc = (c->hist + 1) % 3;
+    const int gnew = 1 - c->gcur;
+    if (p->temporal_enable) {
+        TemporalArgs t;
+        t.in_rgb = in; t.gbuf = g; t.cv_hist = c->cv[c->hist]; t.cv_acc = c->cv[acc];
+        t.mom_hist = c->mom[c->cur]; t.mom_acc = c->mom[1 - c->cur];
+        t.hlen = c->hlen[c->cur]; t.hlen_upd = c->hlen[1 - c->cur];
+        t.nrm_prev = c->nrm[c->gcur]; t.gid_prev = c->gid[c->gcur];
+        t.nrm_cur = c->nrm[gnew]; t.gid_cur = c->gid[gnew]; t.pos_cur = c->pos;
+        memcpy(t.M, c->view_prev, sizeof(t.M));
+        t.W = c->W; t.H = c->H; t.color_alpha_min = p->color_alpha; t.moment_alpha_min = p->moment_alpha;
+        LAUNCH(SVGF_KERNEL_TEMPORAL, launch_temporal(t, s));
+    } else {
+        LAUNCH(SVGF_KERNEL_PREPARE, launch_prepare(in, g, c->cv[acc], c->nrm[gnew], c->gid[gnew], c->pos, c->W, c->H, s));
+    }
+    c->acc = acc;
+    c->hist = acc;                                   // color_history <- color_acc / input (:366,370)
+    if (c->capture) HIPC(c, hipMemcpyAsync(c->cv_capture, c->cv[acc], c->n * sizeof(float4), hipMemcpyDeviceToDevice, s));
+
+    // 2) debug views, pass-through or the a-trous cascade (:373-394)
+    if (p->right_view_option == 1) {
+        LAUNCH(SVGF_KERNEL_DEBUGVIEW, launch_debug_hlen(c->hlen[c->cur], out, n, 100.0f, s));   // pre-update lengths (:374)
+    } else if (p->right_view_option == 2) {
+        LAUNCH(SVGF_KERNEL_DEBUGVIEW, launch_debug_var(c->cv[acc], out, n, 0.1f, s));            // (:377)
+    } else if (p->atrous_nlevel == 0 || !p->spatial_enable) {
+        LAUNCH(SVGF_KERNEL_COPYOUT, launch_copy_rgb(c->cv[c->hist], out, n, s));                 // (:382)
+    } else {
+        int src = c->hist;
+        for (int level = 1; level <= p->atrous_nlevel; level++) {
+            const bool last = (level == p->atrous_nlevel);
+            const bool keep = (level == p->history_level);      // this level's output becomes the colour history (:391)
+            int dst = -1;
+            if (!last || keep) {
+                for (int k = 0; k < 3; k++) if (k != src && k != c->hist) { dst = k; break; }
+            }
+            AtrousArgs a;
+            a.src = c->cv[src]; a.dst = dst >= 0 ? c->cv[dst] : nullptr; a.out_rgb = last ? out : nullptr;
+            a.nrm = c->nrm[gnew]; a.pos = c->pos; a.gbuf = g;
+            a.W = c->W; a.H = c->H; a.step = 1 << level;        // level starts at 1 => steps 2,4,8,16,32 (:98,386)
+            a.sigma_c = p->sigma_l; a.sigma_n = p->sigma_n; a.sigma_x = p->sigma_x;
+            a.blur_variance = p->blur_variance ? 1 : 0;
+            a.modulate = (last && p->sepcolor && p->addcolor) ? 1 : 0;
+            bool strip = false;
+            if (p->kernel_variant != 1) {
+                strip = atrous_strip_supported(a);
+                if (!strip && p->kernel_variant == 2) {
+                    snprintf(c->err, sizeof(c->err), "svgf_denoise: strip kernel does not support %dx%d step %d", c->W, c->H, a.step);
+                    return SVGF_ERR_UNSUPPORTED;
+                }
+            }
+            if (strip) LAUNCH(SVGF_KERNEL_ATROUS, launch_atrous_strip(a, s));
+            else       LAUNCH(SVGF_KERNEL_ATROUS, launch_atrous_gather(a, s));
+            if (keep) c->hist = dst;
+            src = dst;
+        }
+    }
+
+    // 3) history rotation (:396-399): planes swap roles instead of being copied
+    if (p->temporal_enable) c->cur = 1 - c->cur;
+    c->gcur = gnew;
+    view_matrix_from_camera(cam, c->view_prev);
+    if (c->prof_frames) c->prof_count++;
+    return SVGF_OK;
+}
+
+extern "C" int svgf_denoise_host(svgf_ctx *c, float *out_rgb_host, const float *in_rgb_host,
+                                 const SvgfGBufferTexel *gbuffer_host, const SvgfCamera *cam, const SvgfParams *p)
+{
+    if (!c) return SVGF_ERR_INVALID_ARG;
+    if (!out_rgb_host || !in_rgb_host || !gbuffer_host) {
+        snprintf(c->err, sizeof(c->err), "svgf_denoise_host: null argument");
+        return SVGF_ERR_INVALID_ARG;
+    }
+    HIPC(c, hipSetDevice(c->device));
+    if (!c->st_in) HIPC(c, hipMalloc((void **)&c->st_in, c->n * 3 * sizeof(float)));
+    if (!c->st_out) HIPC(c, hipMalloc((void **)&c->st_out, c->n * 3 * sizeof(float)));
+    if (!c->st_g) HIPC(c, hipMalloc((void **)&c->st_g, c->n * sizeof(SvgfGBufferTexel)));
+    HIPC(c, hipMemcpy(c->st_in, in_rgb_host, c->n * 3 * sizeof(float), hipMemcpyHostToDevice));
+    HIPC(c, hipMemcpy(c->st_g, gbuffer_host, c->n * sizeof(SvgfGBufferTexel), hipMemcpyHostToDevice));
+    int rc = svgf_denoise(c, c->st_out, c->st_in, c->st_g, cam, p, nullptr);
+    if (rc != SVGF_OK) return rc;
+    HIPC(c, hipDeviceSynchronize());
+    HIPC(c, hipMemcpy(out_rgb_host, c->st_out, c->n * 3 * sizeof(float), hipMemcpyDeviceToHost));
+    return SVGF_OK;
+}
+
+// ---- state inspection -------------------------------------------------------------------------------------------
+
+extern "C" int svgf_read_state(svgf_ctx *c, int which, void *host_dst, unsigned long long host_bytes)
+{
+    if (!c || !host_dst) return SVGF_ERR_INVALID_ARG;
+    HIPC(c, hipSetDevice(c->device));
+    HIPC(c, hipDeviceSynchronize());
+    const size_t n = c->n;
+    auto need = [&](size_t b) -> bool {
+        if (host_bytes < b) { snprintf(c->err, sizeof(c->err), "svgf_read_state: buffer too small (%llu < %zu)", host_bytes, b); return false; }
+        return true;
+    };
+    switch (which) {
+    case SVGF_STATE_HISTORY_LENGTH:
+        if (!need(n * sizeof(int))) return SVGF_ERR_INVALID_ARG;
+        HIPC(c, hipMemcpy(host_dst, c->hlen[c->cur], n * sizeof(int), hipMemcpyDeviceToHost));
+        return SVGF_OK;
+    case SVGF_STATE_MOMENTS:
+        if (!need(n * 2 * sizeof(float))) return SVGF_ERR_INVALID_ARG;
+        HIPC(c, hipMemcpy(host_dst, c->mom[c->cur], n * 2 * sizeof(float), hipMemcpyDeviceToHost));
+        return SVGF_OK;
+    case SVGF_STATE_COLOR_HISTORY:
+    case SVGF_STATE_COLOR_ACC:
+    case SVGF_STATE_VARIANCE_TEMPORAL: {
+        const bool is_hist = (which == SVGF_STATE_COLOR_HISTORY);
+        if (!is_hist && !c->cv_capture) {
+            snprintf(c->err, sizeof(c->err), "svgf_read_state: enable svgf_set_capture before the frame");
+            return SVGF_ERR_INVALID_ARG;
+        }
+        const size_t out_bytes = (which == SVGF_STATE_VARIANCE_TEMPORAL) ? n * sizeof(float) : n * 3 * sizeof(float);
+        if (!need(out_bytes)) return SVGF_ERR_INVALID_ARG;
+        float4 *tmp = (float4 *)malloc(n * sizeof(float4));
+        if (!tmp) return SVGF_ERR_OOM;
+        hipError_t e = hipMemcpy(tmp, is_hist ? c->cv[c->hist] : c->cv_capture, n * sizeof(float4), hipMemcpyDeviceToHost);
+        if (e != hipSuccess) { free(tmp); snprintf(c->err, sizeof(c->err), "hipMemcpy: %s", hipGetErrorString(e)); return SVGF_ERR_HIP; }
+        float *d = (float *)host_dst;
+        if (which == SVGF_STATE_VARIANCE_TEMPORAL) for (size_t k = 0; k < n; k++) d[k] = tmp[k].w;
+        else for (size_t k = 0; k < n; k++) { d[3 * k] = tmp[k].x; d[3 * k + 1] = tmp[k].y; d[3 * k + 2] = tmp[k].z; }
+        free(tmp);
+        return SVGF_OK;
+    }
+    default:
+        snprintf(c->err, sizeof(c->err), "svgf_read_state: unknown state %d", which);
+        return SVGF_ERR_INVALID_ARG;
+    }
+}

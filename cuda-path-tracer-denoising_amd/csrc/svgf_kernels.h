@@ -1,0 +1,53 @@
+// svgf_kernels.h — launch wrappers shared between the host orchestration (svgf_api.hip) and the
+// kernel translation units.  Internal; the public boundary is include/svgf.h.
+//
+// Device data layout (all planes W*H elements, index p = x + y*W, resident in HBM for the context's life):
+//   CV[k]   float4 {r, g, b, variance}   colour+variance planes; ping-pong / colour history (16 B/px each)
+//   NRM[k]  packed float3 normal         current / previous frame (12 B/px each)
+//   GID[k]  int geomId                   current / previous frame (4 B/px each)
+//   POS     packed float3 position       current frame (12 B/px)
+//   MOM[k]  float2 {m1, m2}              moment history / accumulation (8 B/px each)
+//   HLEN[k] int                          history length / update (4 B/px each)
+// The 52-byte AoS G-buffer texel of the boundary (reference src/sceneStructs.h:113-119) is read exactly once per
+// frame, by the temporal (or prepare) kernel, which splits it into the NRM/POS/GID planes the a-trous levels read.
+#pragma once
+#include <hip/hip_runtime.h>
+
+struct AtrousArgs {
+    const float4 *src;        // CV plane read (colour + variance snapshot)
+    float4 *dst;              // CV plane written, may be null on the last level
+    float *out_rgb;           // packed rgb output (user buffer), null except on the last level
+    const float *nrm;         // packed float3
+    const float *pos;         // packed float3
+    const float *gbuf;        // raw 52-B texels, only read when modulate != 0 (albedo*ialbedo, reference :166-168)
+    int W, H, step;
+    float sigma_c, sigma_n, sigma_x;
+    int blur_variance;
+    int modulate;
+};
+
+struct TemporalArgs {
+    const float *in_rgb;      // packed rgb, current 1-spp colour
+    const float *gbuf;        // raw 52-B texels
+    const float4 *cv_hist;    // colour history (rgb used)
+    float4 *cv_acc;           // out: {colour_acc, variance}
+    const float2 *mom_hist; float2 *mom_acc;
+    const int *hlen; int *hlen_upd;
+    const float *nrm_prev; const int *gid_prev;
+    float *nrm_cur; int *gid_cur; float *pos_cur;
+    float M[16];              // previous view matrix, column-major
+    int W, H;
+    float color_alpha_min, moment_alpha_min;
+};
+
+hipError_t launch_temporal(const TemporalArgs &a, hipStream_t s);
+// non-temporal mode: variance = 10, colour = input, split G-buffer (reference EstimateVariance :320-329 + :370)
+hipError_t launch_prepare(const float *in_rgb, const float *gbuf, float4 *cv, float *nrm, int *gid, float *pos,
+                          int W, int H, hipStream_t s);
+hipError_t launch_atrous_gather(const AtrousArgs &a, hipStream_t s);   // strict one-thread-per-pixel gather kernel
+hipError_t launch_atrous_strip(const AtrousArgs &a, hipStream_t s);    // LDS strip-marching kernel (fast path)
+bool       atrous_strip_supported(const AtrousArgs &a);
+// out = float(value)/scale broadcast to rgb (reference DebugView :331-340)
+hipError_t launch_debug_hlen(const int *hlen, float *out_rgb, int n, float scale, hipStream_t s);
+hipError_t launch_debug_var(const float4 *cv, float *out_rgb, int n, float scale, hipStream_t s);
+hipError_t launch_copy_rgb(const float4 *cv, float *out_rgb, int n, hipStream_t s);   // reference :382

@@ -1,0 +1,308 @@
+// svgf_kernels.hip — temporal accumulation, G-buffer split, strict a-trous gather, debug/copy kernels (gfx950).
+//
+// The temporal kernel and the strict gather kernel keep the reference's arithmetic order and double promotions
+// (reference src/denoise.cu:121,138,143-145,159,196,252) with FMA contraction off, so that they agree with the CPU
+// oracle to the last ulp except inside expf.  They are the correctness anchors; the bandwidth-shaped a-trous
+// kernel lives in svgf_atrous_strip.hip.
+#include "svgf_kernels.h"
+
+#define SVGF_BLOCK 256
+
+static inline int div_up(long long a, int b) { return (int)((a + b - 1) / b); }
+
+// ----------------------------------------------------------------------------------------------------
+// helpers
+// ----------------------------------------------------------------------------------------------------
+
+// luminance with the reference's double promotion (src/denoise.cu:121,138,196)
+__device__ __forceinline__ float lum_strict(float r, float g, float b)
+{
+#pragma clang fp contract(off)
+    double l = 0.2126 * (double)r + 0.7152 * (double)g;
+    l = l + 0.0722 * (double)b;
+    return (float)l;
+}
+
+// glm::distance(vec3,vec3): sqrt((dx*dx + dy*dy) + dz*dz)
+__device__ __forceinline__ float dist3_strict(float ax, float ay, float az, float bx, float by, float bz)
+{
+#pragma clang fp contract(off)
+    float dx = bx - ax, dy = by - ay, dz = bz - az;
+    float s = dx * dx + dy * dy;
+    s = s + dz * dz;
+    return sqrtf(s);
+}
+
+// ----------------------------------------------------------------------------------------------------
+// temporal accumulation  (reference BackProjection src/denoise.cu:185-317, isReprjValid :172-182)
+// One thread per pixel; the history taps are a data-dependent gather around the reprojected position, served
+// by L1/L2 (neighbouring pixels reproject to neighbouring taps).  Also splits the 52-B texel into planes.
+// ----------------------------------------------------------------------------------------------------
+
+__device__ __forceinline__ int reproj_valid(const TemporalArgs &a, float qx, float qy, int gid, float nx, float ny, float nz)
+{
+    if (!(qx == qx) || !(qy == qy)) return -1;                      // NaN coordinate: defined as invalid
+    if (qx < 0.0f || qx >= (float)a.W || qy < 0.0f || qy >= (float)a.H) return -1;
+    int q = (int)qx + (int)qy * a.W;
+    int gq = a.gid_prev[q];
+    if (gq == -1 || gq != gid) return -1;
+    const float *n = a.nrm_prev + 3 * (size_t)q;
+    if (dist3_strict(n[0], n[1], n[2], nx, ny, nz) > 1e-1f) return -1;
+    return q;
+}
+
+__global__ __launch_bounds__(SVGF_BLOCK) void k_temporal(TemporalArgs a)
+{
+#pragma clang fp contract(off)
+    const int n = a.W * a.H;
+    const int p = blockIdx.x * SVGF_BLOCK + threadIdx.x;
+    if (p >= n) return;
+
+    const float *t = a.gbuf + 13 * (size_t)p;
+    const float nx = t[0], ny = t[1], nz = t[2];
+    const float px = t[3], py = t[4], pz = t[5];
+    const int gid = __float_as_int(t[12]);
+    a.nrm_cur[3 * (size_t)p] = nx; a.nrm_cur[3 * (size_t)p + 1] = ny; a.nrm_cur[3 * (size_t)p + 2] = nz;
+    a.pos_cur[3 * (size_t)p] = px; a.pos_cur[3 * (size_t)p + 1] = py; a.pos_cur[3 * (size_t)p + 2] = pz;
+    a.gid_cur[p] = gid;
+
+    const float cr = a.in_rgb[3 * (size_t)p], cg = a.in_rgb[3 * (size_t)p + 1], cb = a.in_rgb[3 * (size_t)p + 2];
+    const float lum = lum_strict(cr, cg, cb);
+    const int N = a.hlen[p];
+
+    if (N > 0 && gid != -1) {
+        // previous-frame view space; glm mat4*vec4 association (m0 v0 + m1 v1) + (m2 v2 + m3 v3)
+        float vs[3];
+#pragma unroll
+        for (int r = 0; r < 3; r++) {
+            float a0 = a.M[0 * 4 + r] * px + a.M[1 * 4 + r] * py;
+            float a1 = a.M[2 * 4 + r] * pz + a.M[3 * 4 + r] * 1.0f;
+            vs[r] = a0 + a1;
+        }
+        float clipx = vs[0] / vs[2], clipy = vs[1] / vs[2];          // no tan(fov), no aspect (:202-203)
+        float ndcx = -clipx * 0.5f + 0.5f, ndcy = -clipy * 0.5f + 0.5f;
+        float prevx = ndcx * (float)a.W - 0.5f, prevy = ndcy * (float)a.H - 0.5f;
+        float fx = floorf(prevx), fy = floorf(prevy);
+        float fracx = prevx - fx, fracy = prevy - fy;
+
+        bool valid = (fx >= 0.0f && fy >= 0.0f && fx < (float)a.W && fy < (float)a.H);
+        int q4[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            q4[k] = reproj_valid(a, fx + (float)(k & 1), fy + (float)(k >> 1), gid, nx, ny, nz);
+            valid = valid && (q4[k] >= 0);
+        }
+
+        float pc0 = 0.0f, pc1 = 0.0f, pc2 = 0.0f, pm0 = 0.0f, pm1 = 0.0f, plen = 0.0f;
+        if (valid) {                                                  // bilinear (:234-259)
+            float w[4] = { (1 - fracx) * (1 - fracy), fracx * (1 - fracy), (1 - fracx) * fracy, fracx * fracy };
+            float sumw = 0.0f;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int q = q4[k];
+                const float4 ch = a.cv_hist[q];
+                const float2 mh = a.mom_hist[q];
+                pc0 += w[k] * ch.x; pc1 += w[k] * ch.y; pc2 += w[k] * ch.z;
+                pm0 += w[k] * mh.x; pm1 += w[k] * mh.y;
+                plen += w[k] * (float)a.hlen[q];
+                sumw += w[k];
+            }
+            if ((double)sumw >= 0.01) {
+                pc0 /= sumw; pc1 /= sumw; pc2 /= sumw; pm0 /= sumw; pm1 /= sumw; plen /= sumw;
+            }
+        } else {                                                      // 3x3 box around floor (:262-286)
+            float cnt = 0.0f;
+            for (int yy = -1; yy <= 1; yy++)
+                for (int xx = -1; xx <= 1; xx++) {
+                    const int q = reproj_valid(a, fx + (float)xx, fy + (float)yy, gid, nx, ny, nz);
+                    if (q >= 0) {
+                        const float4 ch = a.cv_hist[q];
+                        const float2 mh = a.mom_hist[q];
+                        pc0 += ch.x; pc1 += ch.y; pc2 += ch.z;
+                        pm0 += mh.x; pm1 += mh.y;
+                        plen += (float)a.hlen[q];
+                        cnt += 1.0f;
+                    }
+                }
+            if (cnt > 0.0f) {
+                pc0 /= cnt; pc1 /= cnt; pc2 /= cnt; pm0 /= cnt; pm1 /= cnt; plen /= cnt;
+                valid = true;
+            }
+        }
+
+        if (valid) {
+            const float ca = fmaxf(1.0f / (float)(N + 1), a.color_alpha_min);   // alpha on the current side (:297)
+            const float ma = fmaxf(1.0f / (float)(N + 1), a.moment_alpha_min);  // alpha on the history side (:300-301)
+            a.hlen_upd[p] = (int)plen + 1;
+            const float m1 = ma * pm0 + (1.0f - ma) * lum;
+            const float m2 = ma * pm1 + ((1.0f - ma) * lum) * lum;
+            a.mom_acc[p] = make_float2(m1, m2);
+            const float v = m2 - m1 * m1;
+            a.cv_acc[p] = make_float4(cr * ca + pc0 * (1.0f - ca), cg * ca + pc1 * (1.0f - ca),
+                                      cb * ca + pc2 * (1.0f - ca), v > 0.0f ? v : 0.0f);
+            return;
+        }
+    }
+    a.hlen_upd[p] = 1;                                                // no usable history (:311-315)
+    a.mom_acc[p] = make_float2(lum, lum * lum);
+    a.cv_acc[p] = make_float4(cr, cg, cb, 100.0f);
+}
+
+hipError_t launch_temporal(const TemporalArgs &a, hipStream_t s)
+{
+    const long long n = (long long)a.W * a.H;
+    hipLaunchKernelGGL(k_temporal, dim3(div_up(n, SVGF_BLOCK)), dim3(SVGF_BLOCK), 0, s, a);
+    return hipGetLastError();
+}
+
+// ----------------------------------------------------------------------------------------------------
+// non-temporal prepare: variance = 10 (reference EstimateVariance :320-329), colour = input (:370), split texel
+// ----------------------------------------------------------------------------------------------------
+
+__global__ __launch_bounds__(SVGF_BLOCK) void k_prepare(const float *__restrict__ in_rgb, const float *__restrict__ gbuf,
+                                                       float4 *__restrict__ cv, float *__restrict__ nrm,
+                                                       int *__restrict__ gid, float *__restrict__ pos, int n)
+{
+    const int p = blockIdx.x * SVGF_BLOCK + threadIdx.x;
+    if (p >= n) return;
+    const float *t = gbuf + 13 * (size_t)p;
+    nrm[3 * (size_t)p] = t[0]; nrm[3 * (size_t)p + 1] = t[1]; nrm[3 * (size_t)p + 2] = t[2];
+    pos[3 * (size_t)p] = t[3]; pos[3 * (size_t)p + 1] = t[4]; pos[3 * (size_t)p + 2] = t[5];
+    gid[p] = __float_as_int(t[12]);
+    cv[p] = make_float4(in_rgb[3 * (size_t)p], in_rgb[3 * (size_t)p + 1], in_rgb[3 * (size_t)p + 2], 10.0f);
+}
+
+hipError_t launch_prepare(const float *in_rgb, const float *gbuf, float4 *cv, float *nrm, int *gid, float *pos,
+                          int W, int H, hipStream_t s)
+{
+    const long long n = (long long)W * H;
+    hipLaunchKernelGGL(k_prepare, dim3(div_up(n, SVGF_BLOCK)), dim3(SVGF_BLOCK), 0, s, in_rgb, gbuf, cv, nrm, gid, pos, (int)n);
+    return hipGetLastError();
+}
+
+// ----------------------------------------------------------------------------------------------------
+// strict a-trous gather  (reference ATrousFilter src/denoise.cu:77-170), snapshot variance semantics:
+// variance is read from src.w and written to dst.w, never in place.
+// ----------------------------------------------------------------------------------------------------
+
+__global__ __launch_bounds__(SVGF_BLOCK) void k_atrous_gather(AtrousArgs a)
+{
+#pragma clang fp contract(off)
+    const int n = a.W * a.H;
+    const int p = blockIdx.x * SVGF_BLOCK + threadIdx.x;
+    if (p >= n) return;
+    const int x = p % a.W, y = p / a.W;
+
+    const float4 cp = a.src[p];
+    float var;
+    if (a.blur_variance) {                                            // 3x3 gaussian, borders renormalised (:102-118)
+        float sum = 0.0f, sumw = 0.0f;
+        for (int dy = -1; dy <= 1; dy++)
+            for (int dx = -1; dx <= 1; dx++) {
+                const int lx = x + dx, ly = y + dy;
+                if (lx >= 0 && ly >= 0 && lx < a.W && ly < a.H) {
+                    const float gw = (float)((2 - (dx & 1)) * (2 - (dy & 1))) * 0.0625f;   // [1 2 1]x[1 2 1]/16
+                    sum += gw * a.src[lx + ly * a.W].w;
+                    sumw += gw;
+                }
+            }
+        var = fmaxf(sum / sumw, 0.0f);
+    } else {
+        var = fmaxf(cp.w, 0.0f);
+    }
+
+    const float lp = lum_strict(cp.x, cp.y, cp.z);
+    const float npx = a.nrm[3 * (size_t)p], npy = a.nrm[3 * (size_t)p + 1], npz = a.nrm[3 * (size_t)p + 2];
+    const float ppx = a.pos[3 * (size_t)p], ppy = a.pos[3 * (size_t)p + 1], ppz = a.pos[3 * (size_t)p + 2];
+
+    const double den_l = (double)(sqrtf(var) * a.sigma_c) + 1e-6;
+    const double den_n = (double)a.sigma_n + 1e-6;
+    const double den_x = (double)a.sigma_x + 1e-6;
+
+    float c0 = 0.0f, c1 = 0.0f, c2 = 0.0f, vsum = 0.0f, wsum = 0.0f, w2sum = 0.0f;
+    for (int i = -2; i <= 2; i++) {
+        for (int j = -2; j <= 2; j++) {
+            const int xq = x + a.step * i, yq = y + a.step * j;
+            if (xq < 0 || xq >= a.W || yq < 0 || yq >= a.H) continue;
+            const int q = xq + yq * a.W;
+            const float4 cq = a.src[q];
+            const float lq = lum_strict(cq.x, cq.y, cq.z);
+            const float *nq = a.nrm + 3 * (size_t)q;
+            const float *pq = a.pos + 3 * (size_t)q;
+            const float wl = expf((float)(-(double)fabsf(lq - lp) / den_l));
+            const float wn = fminf(1.0f, expf((float)(-(double)dist3_strict(npx, npy, npz, nq[0], nq[1], nq[2]) / den_n)));
+            const float wx = fminf(1.0f, expf((float)(-(double)dist3_strict(ppx, ppy, ppz, pq[0], pq[1], pq[2]) / den_x)));
+            const float hi = (i == 0) ? 6.0f : ((i == 1 || i == -1) ? 4.0f : 1.0f);
+            const float hj = (j == 0) ? 6.0f : ((j == 1 || j == -1) ? 4.0f : 1.0f);
+            float w = (hi * hj * (1.0f / 256.0f)) * wl;                 // h[k] exact in fp32
+            w = w * wn;
+            w = w * wx;
+            wsum += w;
+            w2sum += w * w;
+            c0 += cq.x * w; c1 += cq.y * w; c2 += cq.z * w;
+            vsum += (cq.w * w) * w;
+        }
+    }
+
+    float o0, o1, o2, ov;
+    if ((double)wsum > 10e-6) {                                       // NaN -> false -> pass-through (:159-164)
+        o0 = c0 / wsum; o1 = c1 / wsum; o2 = c2 / wsum; ov = vsum / w2sum;
+    } else {
+        o0 = cp.x; o1 = cp.y; o2 = cp.z; ov = cp.w;
+    }
+    if (a.modulate) {                                                 // last level: * albedo * ialbedo (:166-168)
+        const float *t = a.gbuf + 13 * (size_t)p;
+        o0 *= t[6] * t[9]; o1 *= t[7] * t[10]; o2 *= t[8] * t[11];
+    }
+    if (a.dst) a.dst[p] = make_float4(o0, o1, o2, ov);
+    if (a.out_rgb) { a.out_rgb[3 * (size_t)p] = o0; a.out_rgb[3 * (size_t)p + 1] = o1; a.out_rgb[3 * (size_t)p + 2] = o2; }
+}
+
+hipError_t launch_atrous_gather(const AtrousArgs &a, hipStream_t s)
+{
+    const long long n = (long long)a.W * a.H;
+    hipLaunchKernelGGL(k_atrous_gather, dim3(div_up(n, SVGF_BLOCK)), dim3(SVGF_BLOCK), 0, s, a);
+    return hipGetLastError();
+}
+
+// ----------------------------------------------------------------------------------------------------
+// debug views (reference DebugView :331-340) and pass-through copy (:382)
+// ----------------------------------------------------------------------------------------------------
+
+__global__ __launch_bounds__(SVGF_BLOCK) void k_debug_hlen(const int *__restrict__ hlen, float *__restrict__ out, int n, float scale)
+{
+    const int p = blockIdx.x * SVGF_BLOCK + threadIdx.x;
+    if (p >= n) return;
+    const float v = (float)hlen[p] / scale;
+    out[3 * (size_t)p] = v; out[3 * (size_t)p + 1] = v; out[3 * (size_t)p + 2] = v;
+}
+__global__ __launch_bounds__(SVGF_BLOCK) void k_debug_var(const float4 *__restrict__ cv, float *__restrict__ out, int n, float scale)
+{
+    const int p = blockIdx.x * SVGF_BLOCK + threadIdx.x;
+    if (p >= n) return;
+    const float v = cv[p].w / scale;
+    out[3 * (size_t)p] = v; out[3 * (size_t)p + 1] = v; out[3 * (size_t)p + 2] = v;
+}
+__global__ __launch_bounds__(SVGF_BLOCK) void k_copy_rgb(const float4 *__restrict__ cv, float *__restrict__ out, int n)
+{
+    const int p = blockIdx.x * SVGF_BLOCK + threadIdx.x;
+    if (p >= n) return;
+    const float4 c = cv[p];
+    out[3 * (size_t)p] = c.x; out[3 * (size_t)p + 1] = c.y; out[3 * (size_t)p + 2] = c.z;
+}
+
+hipError_t launch_debug_hlen(const int *hlen, float *out_rgb, int n, float scale, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_debug_hlen, dim3(div_up(n, SVGF_BLOCK)), dim3(SVGF_BLOCK), 0, s, hlen, out_rgb, n, scale);
+    return hipGetLastError();
+}
+hipError_t launch_debug_var(const float4 *cv, float *out_rgb, int n, float scale, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_debug_var, dim3(div_up(n, SVGF_BLOCK)), dim3(SVGF_BLOCK), 0, s, cv, out_rgb, n, scale);
+    return hipGetLastError();
+}
+hipError_t launch_copy_rgb(const float4 *cv, float *out_rgb, int n, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_copy_rgb, dim3(div_up(n, SVGF_BLOCK)), dim3(SVGF_BLOCK), 0, s, cv, out_rgb, n);
+    return hipGetLastError();
+}

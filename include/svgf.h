@@ -1,0 +1,156 @@
+/*
+ * svgf.h — C ABI of the MI355X-native SVGF denoiser (libsvgf_hip.so).
+ *
+ * This is the drop-in boundary for the reference's denoiser entry points
+ *     void denoiseInit(Scene *scene);                         (reference src/denoise.h:6,  src/denoise.cu:31-61)
+ *     void denoiseFree();                                     (reference src/denoise.h:7,  src/denoise.cu:63-74)
+ *     void denoise(glm::vec3 *out, glm::vec3 *in,
+ *                  GBufferTexel *gbuffer);                    (reference src/denoise.h:8,  src/denoise.cu:349-402)
+ * The reference keeps its state in file-static globals and reads 13 `ui_*`
+ * globals + `scene->state.camera` at call time (src/main.h:39-69, src/denoise.cu:350-399).
+ * Here the same information crosses the boundary explicitly: a context handle
+ * (so one context per GPU can coexist), a camera block and a parameter block.
+ * `include/denoise_compat.h` + `cuda-path-tracer-denoising_amd/csrc/denoise_compat.cpp`
+ * rebuild the three legacy functions on top of these entry points.
+ *
+ * Plain C: pointers and sizes only, no C++/torch types.  All image pointers are
+ * DEVICE pointers unless the function name ends in `_host`.
+ *
+ * Wire formats (kept bit-identical to the reference):
+ *   colour image : W*H packed float[3]  (glm::vec3, 12 B), index p = x + y*W   (src/pathtrace.cu:193)
+ *   G-buffer     : W*H SvgfGBufferTexel (52 B, align 4)                        (src/sceneStructs.h:113-119)
+ */
+#ifndef SVGF_H_
+#define SVGF_H_
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SVGF_VERSION_MAJOR 0
+#define SVGF_VERSION_MINOR 1
+
+/* ---- error codes (every entry point returns one of these; the library never exits) ---- */
+#define SVGF_OK                 0
+#define SVGF_ERR_INVALID_ARG   -1
+#define SVGF_ERR_NO_DEVICE     -2   /* no usable HIP device / HIP runtime error at create */
+#define SVGF_ERR_OOM           -3
+#define SVGF_ERR_HIP           -4   /* a HIP call or kernel launch failed; see svgf_last_error */
+#define SVGF_ERR_UNSUPPORTED   -5
+
+/* G-buffer texel, layout of reference `struct GBufferTexel` (src/sceneStructs.h:113-119):
+ * normal@0 position@12 albedo@24 ialbedo@36 geomId@48, sizeof == 52, alignof == 4.
+ * geomId == -1 marks a ray miss (src/pathtrace.cu:317-323). */
+typedef struct SvgfGBufferTexel {
+    float normal[3];
+    float position[3];
+    float albedo[3];
+    float ialbedo[3];
+    int   geomId;
+} SvgfGBufferTexel;
+
+/* The camera fields `denoise()` reads from `scene->state.camera`
+ * (src/sceneStructs.h:74-83; used at src/denoise.cu:33-34,343-346,350-351).
+ * right/up are NOT normalised in the reference app (src/main.cpp:180-184); pass them as they are. */
+typedef struct SvgfCamera {
+    float right[3];
+    float up[3];
+    float view[3];
+    float position[3];
+} SvgfCamera;
+
+/* The `ui_*` globals `denoise()` reads (src/main.h:39-69, defaults src/main.cpp:49-62). */
+typedef struct SvgfParams {
+    int   temporal_enable;    /* ui_temporal_enable  (default 0) */
+    int   spatial_enable;     /* ui_spatial_enable   (default 0) */
+    float color_alpha;        /* ui_color_alpha      (0.2)  */
+    float moment_alpha;       /* ui_moment_alpha     (0.2)  */
+    int   blur_variance;      /* ui_blurvariance     (1)    */
+    float sigma_l;            /* ui_sigmal           (0.45) luminance edge-stop */
+    float sigma_x;            /* ui_sigmax           (0.35) position  edge-stop */
+    float sigma_n;            /* ui_sigman           (0.2)  normal    edge-stop */
+    int   atrous_nlevel;      /* ui_atrous_nlevel    (5), 0..SVGF_MAX_LEVELS */
+    int   history_level;      /* ui_history_level    (1)    */
+    int   sepcolor;           /* ui_sepcolor         (0)    */
+    int   addcolor;           /* ui_addcolor         (0)    */
+    int   right_view_option;  /* ui_right_view_option (0): 0 image, 1 history length, 2 variance */
+    /* --- extensions; 0 == reference behaviour --- */
+    int   kernel_variant;     /* 0 auto (fastest), 1 strict gather kernel, 2 LDS strip kernel */
+    int   reserved[3];
+} SvgfParams;
+
+#define SVGF_MAX_LEVELS 10
+
+typedef struct svgf_ctx svgf_ctx;
+
+/* Library / ABI version: (major << 16) | minor. */
+int svgf_version(void);
+
+/* Fill *p with the reference defaults of src/main.cpp:49-62. */
+int svgf_params_default(SvgfParams *p);
+
+/* denoiseInit equivalent: allocate per-pixel history state for a width x height image on HIP
+ * device `device` and zero the history (src/denoise.cu:31-61).  *out receives the handle. */
+int svgf_create(int device, int width, int height, svgf_ctx **out);
+
+/* denoiseFree equivalent (src/denoise.cu:63-74).  NULL is accepted. */
+int svgf_destroy(svgf_ctx *ctx);
+
+/* denoiseFree + denoiseInit on the same size (what runCuda() does on reset, src/main.cpp:192-201):
+ * history length, moments and variance go back to zero; nothing is reallocated. */
+int svgf_reset(svgf_ctx *ctx);
+
+/* denoise() equivalent (src/denoise.cu:349-402).  Enqueues the whole frame on `stream`
+ * (a hipStream_t, NULL = default stream) and returns WITHOUT synchronising; the legacy
+ * shim adds the hipDeviceSynchronize() the reference ends with (src/denoise.cu:401).
+ * `cam` is the camera of THIS frame; it is retained as the previous view for the next call
+ * (src/denoise.cu:399). */
+int svgf_denoise(svgf_ctx *ctx, void *out_rgb_dev, const void *in_rgb_dev,
+                 const void *gbuffer_dev, const SvgfCamera *cam, const SvgfParams *params,
+                 void *stream);
+
+/* Convenience for tests/tools: same call with HOST pointers (uploads, runs, downloads, syncs). */
+int svgf_denoise_host(svgf_ctx *ctx, float *out_rgb_host, const float *in_rgb_host,
+                      const SvgfGBufferTexel *gbuffer_host, const SvgfCamera *cam,
+                      const SvgfParams *params);
+
+/* Block until everything enqueued by this context has finished. */
+int svgf_sync(svgf_ctx *ctx);
+
+/* Message of the last error on this context (or of the last failed svgf_create if ctx == NULL). */
+const char *svgf_last_error(const svgf_ctx *ctx);
+
+int svgf_width(const svgf_ctx *ctx);
+int svgf_height(const svgf_ctx *ctx);
+
+/* ---- state inspection (tests, sequence goldens).  All copy W*H elements to HOST memory, synchronously. ---- */
+#define SVGF_STATE_HISTORY_LENGTH   0   /* int32[W*H]   history length that the NEXT frame will read (src/denoise.cu:398) */
+#define SVGF_STATE_MOMENTS          1   /* float[2*W*H] moment history of the NEXT frame (src/denoise.cu:397) */
+#define SVGF_STATE_COLOR_HISTORY    2   /* float[3*W*H] colour history of the NEXT frame (src/denoise.cu:366,370,391) */
+#define SVGF_STATE_VARIANCE_TEMPORAL 3  /* float[W*H]   variance after the temporal pass of the LAST frame (src/denoise.cu:306,315,327) */
+#define SVGF_STATE_COLOR_ACC        4   /* float[3*W*H] colour after the temporal pass of the LAST frame (src/denoise.cu:297,313) */
+int svgf_read_state(svgf_ctx *ctx, int which, void *host_dst, unsigned long long host_bytes);
+
+/* Keep a copy of the temporal pass output of every following frame so that SVGF_STATE_VARIANCE_TEMPORAL and
+ * SVGF_STATE_COLOR_ACC can be read back (costs one extra 16 B/px device copy per frame; tests only). */
+int svgf_set_capture(svgf_ctx *ctx, int on);
+
+/* ---- per-kernel timing with HIP events on the launch stream (bench / roofline) ----
+ * svgf_profile_enable(ctx, nframes): allocate event pairs for `nframes` frames (0 = off) and restart the frame
+ * counter; every following svgf_denoise brackets each kernel it launches with an event pair in slot
+ * (frame_counter % nframes).  No synchronisation happens inside svgf_denoise.
+ * svgf_profile_read(ctx, slot, ...): after a sync, returns for that slot the kernels launched, in launch order:
+ * kind code (SVGF_KERNEL_*) and elapsed milliseconds. */
+#define SVGF_KERNEL_TEMPORAL   1
+#define SVGF_KERNEL_PREPARE    2   /* non-temporal variance fill + G-buffer split */
+#define SVGF_KERNEL_ATROUS     3
+#define SVGF_KERNEL_DEBUGVIEW  4
+#define SVGF_KERNEL_COPYOUT    5
+int svgf_profile_enable(svgf_ctx *ctx, int nframes);
+long long svgf_profile_frames(const svgf_ctx *ctx);
+int svgf_profile_read(svgf_ctx *ctx, int slot, int max_entries, int *kinds, float *ms, int *n_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SVGF_H_ */
