@@ -1,0 +1,154 @@
+#!/usr/bin/env python3
+"""bench.py — SVGF Mpixels/s (full pipeline) at 1080p on N GPUs of one node, plus the a-trous kernel's HBM roofline.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+A "step" is one svgf_denoise() call = one full SVGF pass (temporal accumulation + 5 edge-avoiding a-trous levels +
+history rotation) over one 1920x1080 frame of the synthetic Cornell-like sequence (BASELINE.json configs[1]); inputs
+are resident in HBM before the timed region starts.  N > 1: one process and one SVGF context per GPU, every rank
+denoises its own independent sequence (weak scaling, no data-path collective); value = pixels of all ranks / max time.
+
+Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (the a-trous level): algorithmic bytes per launch
+(56 B/pixel) / mean launch duration from HIP events recorded on the launch stream inside the timed
+region.  `cpu_baseline` (N == 1 only) times the CPU oracle — a port, not the product — on the host cores.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as ge  # noqa: E402
+
+W, H = 1920, 1080
+NLEVEL = 5
+ATROUS_BYTES_PER_PIXEL = 56.0      # R: colour 12 + normal 12 + position 12 + variance 4; W: colour 12 + variance 4
+FRAME_BYTES_PER_PIXEL = 404.0      # temporal 124 + 5 x 56
+HBM_PEAK_GBS = 8000.0              # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def cpu_baseline(pkg, frames, params, budget_s=25.0):
+    """CPU oracle (oracle/svgf_oracle.c, OpenMP) on the same workload, bounded sample."""
+    orc = ge.load_oracle()
+    cores = os.cpu_count() or 1
+    threads = min(cores, 64)
+    o = orc.Oracle(pkg, W, H, threads=threads)
+    t_all, n = 0.0, 0
+    t_start = time.perf_counter()
+    for f in range(4):
+        c, g, cam = frames[f % len(frames)]
+        t0 = time.perf_counter()
+        o.denoise(c, g, cam, params)
+        dt = time.perf_counter() - t0
+        if f >= 1:                       # frame 0 has no history (cheaper temporal pass): not representative
+            t_all += dt; n += 1
+        if time.perf_counter() - t_start > budget_s and n >= 1:
+            break
+    o.free()
+    return {"value": round(W * H / (t_all / n) / 1e6, 3), "unit": "Mpixels/s", "cores": threads, "kind": "port",
+            "sample": f"{n} steady-state frames of the same 1920x1080 full-SVGF workload, oracle/svgf_oracle.c "
+                      f"(gcc -O2, OpenMP over rows, {threads} threads of {cores} host cores)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus and world > 1:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    ge.build()
+    pkg = ge.load_package()
+    params = pkg.reference_defaults().set(temporal_enable=1, spatial_enable=1, atrous_nlevel=NLEVEL, history_level=1)
+
+    # every rank owns one independent sequence (its own seed); 4 distinct noisy frames, static camera, resident in HBM
+    seq = pkg.farm.shard(world, world, rank)[0]
+    nsrc = 4
+    frames = [pkg.synth.render_frame(W, H, f, seed=1000 + seq, moving=False) for f in range(nsrc)]
+    d_in = [torch.from_numpy(f[0]).to(dev) for f in frames]
+    d_g = [torch.from_numpy(f[1].view(np.uint8).reshape(-1)).to(dev) for f in frames]
+    cams = [pkg.SvgfCamera.from_dict(f[2]) for f in frames]
+    out = torch.empty((H, W, 3), dtype=torch.float32, device=dev)
+    den = pkg.Denoiser(W, H, device=local_rank)
+    stream = torch.cuda.current_stream(dev)
+    den.profile_enable(a.steps)
+
+    def step(i):
+        k = i % nsrc
+        den.denoise(out, d_in[k], d_g[k], cams[k], params, stream=stream)
+        return W * H
+
+    # warm-up is run with profiling slots too, then the frame counter restarts so slots hold the timed steps only
+    for i in range(a.warmup):
+        step(i)
+    torch.cuda.synchronize(dev)
+    den.profile_enable(a.steps)
+    dt, pixels = pkg.farm.timed_region(step, a.steps, 0, lambda: torch.cuda.synchronize(dev), dist=dist, device=dev)
+
+    # per-kernel durations of the timed steps (HIP events on the launch stream)
+    atrous_ms, temporal_ms = [], []
+    for s in range(min(a.steps, den.profile_frames())):
+        for kind, ms in den.profile_read(s):
+            if kind == pkg.binding.KERNEL_ATROUS:
+                atrous_ms.append(ms)
+            elif kind == pkg.binding.KERNEL_TEMPORAL:
+                temporal_ms.append(ms)
+    if not np.isfinite(out.sum().item()):
+        raise SystemExit("bench: non-finite output")
+
+    if rank == 0:
+        value = pixels / dt / 1e6
+        a_ms = float(np.mean(atrous_ms))
+        achieved = ATROUS_BYTES_PER_PIXEL * W * H / (a_ms * 1e-3) / 1e9
+        line = {
+            "metric": "SVGF Mpixels/s (full pipeline) at 1080p; a-trous HBM GB/s vs roofline",
+            "value": round(value, 2), "unit": "Mpixels/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(dt / a.steps * 1e3, 5), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "cornell-like 1920x1080, full SVGF (temporal + 5 a-trous levels, history_level 1), "
+                                   "static camera, steady-state history; one independent sequence per GPU",
+                       "width": W, "height": H, "atrous_levels": NLEVEL, "parallelism": f"replicas{world}"},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "kernel": "k_atrous_strip (one a-trous level)", "bytes_per_launch": ATROUS_BYTES_PER_PIXEL * W * H,
+                         "mean_launch_us": round(a_ms * 1e3, 2), "launches_timed": len(atrous_ms)},
+            "kernels_us": {"temporal": round(float(np.mean(temporal_ms)) * 1e3, 2), "atrous_level_mean": round(a_ms * 1e3, 2)},
+            "frame_algorithmic_gbs": round(FRAME_BYTES_PER_PIXEL * W * H / (dt / a.steps) / 1e9 / world * 1.0, 1),
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            host_frames = [(f[0], f[1], f[2]) for f in frames]
+            line["cpu_baseline"] = cpu_baseline(pkg, host_frames, params)
+        print(json.dumps(line), flush=True)
+    den.free()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -33,8 +33,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT)
 import __graft_entry__ as ge  # noqa: E402
 
-REF_BIN = os.path.join(ROOT, "oracle", "_ref", "ref_denoise_gpu")
+REF_BIN = os.path.join(ROOT, "oracle", "_ref", "ref_denoise_gpu")              # default hipcc flags (FMA contraction on)
+REF_BIN_NOFMA = os.path.join(ROOT, "oracle", "_ref", "ref_denoise_gpu_nofma")  # -ffp-contract=off
 MAGIC = 0x43475653
+
+KEEP_DEFAULT_BUILD = {"temporal_moving64", "temporal_static96x54", "full_static96x54"}
 
 PARAM_KEYS = ["temporal_enable", "spatial_enable", "color_alpha", "moment_alpha", "blur_variance", "sigma_l",
               "sigma_x", "sigma_n", "atrous_nlevel", "history_level", "sepcolor", "addcolor", "right_view_option"]
@@ -55,7 +58,7 @@ def pack_call(reset, frame_index, p, cam, repeat=0):
                        *[float(v) for k in ("right", "up", "view", "position") for v in cam[k]], int(repeat))
 
 
-def run_reference(W, H, calls, frames, workdir):
+def run_reference(W, H, calls, frames, workdir, binary=None):
     """calls: list of (reset, frame_index, params, cam).  frames: list of (color, gbuffer).  Returns (outs, ms)."""
     os.makedirs(workdir, exist_ok=True)
     case = os.path.join(workdir, "case.bin")
@@ -67,7 +70,7 @@ def run_reference(W, H, calls, frames, workdir):
         for (c, g) in frames:
             f.write(np.ascontiguousarray(c, dtype="<f4").tobytes())
             f.write(np.ascontiguousarray(g).tobytes())
-    r = subprocess.run([REF_BIN, case, outp], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    r = subprocess.run([binary or REF_BIN, case, outp], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
     if r.returncode != 0:
         raise RuntimeError("reference binary failed: " + r.stdout)
     raw = np.fromfile(outp, dtype="<f4")
@@ -97,20 +100,19 @@ def build_cases(pkg):
     cases = []
     S = pkg.synth
 
-    # A. a-trous alone, temporal off (variance == 10 everywhere): every step size, borders, blur on/off
+    # A/B. a-trous alone, temporal off (variance == 10 everywhere): every step size, borders, blur on/off, other sigmas,
+    #      albedo re-modulation; and the first temporal frame + a-trous (variance == 100 everywhere).  One shared input.
     fr, cams = synth_frames(pkg, 96, 96, 1, seed=11, moving=False)
+    runs = {}
     for nl in (1, 2, 3, 5, 7):
-        cases.append(dict(name=f"atrous_synth96_n{nl}", W=96, H=96, frames=fr, cams=cams, race_free=True,
-                          calls=[(1, 0, default_params(spatial_enable=1, atrous_nlevel=nl))],
-                          note="temporal off, spatial on"))
-    cases.append(dict(name="atrous_synth96_n3_noblur", W=96, H=96, frames=fr, cams=cams, race_free=True,
-                      calls=[(1, 0, default_params(spatial_enable=1, atrous_nlevel=3, blur_variance=0))], note=""))
-    cases.append(dict(name="atrous_synth96_n2_sigmas", W=96, H=96, frames=fr, cams=cams, race_free=True,
-                      calls=[(1, 0, default_params(spatial_enable=1, atrous_nlevel=2, sigma_l=0.7, sigma_n=0.05, sigma_x=1.5))],
-                      note="GUI 'default' sigma_l=0.7"))
-    cases.append(dict(name="atrous_synth96_n2_addcolor", W=96, H=96, frames=fr, cams=cams, race_free=True,
-                      calls=[(1, 0, default_params(spatial_enable=1, atrous_nlevel=2, sepcolor=1, addcolor=1))],
-                      note="last level re-modulates by albedo*ialbedo"))
+        runs[f"n{nl}"] = [(1, 0, default_params(spatial_enable=1, atrous_nlevel=nl))]
+    runs["n3_noblur"] = [(1, 0, default_params(spatial_enable=1, atrous_nlevel=3, blur_variance=0))]
+    runs["n2_sigmas"] = [(1, 0, default_params(spatial_enable=1, atrous_nlevel=2, sigma_l=0.7, sigma_n=0.05, sigma_x=1.5))]
+    runs["n2_addcolor"] = [(1, 0, default_params(spatial_enable=1, atrous_nlevel=2, sepcolor=1, addcolor=1))]
+    runs["n0"] = [(1, 0, default_params(spatial_enable=1, atrous_nlevel=0))]
+    runs["frame0_full"] = [(1, 0, default_params(temporal_enable=1, spatial_enable=1))]
+    cases.append(dict(name="atrous_synth96", W=96, H=96, frames=fr, cams=cams, race_free=True, runs=runs,
+                      note="single frame; nK = temporal off + K a-trous levels; frame0_full = temporal on, first frame"))
     fr169, cams169 = synth_frames(pkg, 128, 72, 1, seed=12, moving=False)
     cases.append(dict(name="atrous_synth128x72_n5", W=128, H=72, frames=fr169, cams=cams169, race_free=True,
                       calls=[(1, 0, default_params(spatial_enable=1, atrous_nlevel=5))], note="16:9"))
@@ -139,35 +141,32 @@ def build_cases(pkg):
     cases.append(dict(name="atrous_nancolor40x32_n2", W=40, H=32, frames=[(c, g)], cams=[cam0], race_free=True,
                       calls=[(1, 0, default_params(spatial_enable=1, atrous_nlevel=2))], note="one NaN colour texel"))
 
-    # B. first temporal frame + a-trous (variance == 100 everywhere)
-    cases.append(dict(name="full_frame0_synth96", W=96, H=96, frames=fr, cams=cams, race_free=True,
-                      calls=[(1, 0, default_params(temporal_enable=1, spatial_enable=1))], note="first frame, full SVGF"))
-
     # C. temporal pass alone over sequences: out = colour_acc (spatial off), variance (view 2), history length (view 1)
-    for (nm, W, H, moving) in (("static96", 96, 96, False), ("moving96", 96, 96, True), ("static128x72", 128, 72, False),
-                               ("moving128x72", 128, 72, True)):
+    for (nm, W, H, moving) in (("static64", 64, 64, False), ("moving64", 64, 64, True), ("static96x54", 96, 54, False),
+                               ("moving96x54", 96, 54, True)):
         frs, cs = synth_frames(pkg, W, H, 5, seed=21, moving=moving)
         runs = {}
         for (tag, kw) in (("acc", dict()), ("var", dict(right_view_option=2)), ("hlen", dict(right_view_option=1))):
             runs[tag] = [(1 if f == 0 else 0, f, default_params(temporal_enable=1, spatial_enable=0, **kw)) for f in range(5)]
         cases.append(dict(name=f"temporal_{nm}", W=W, H=H, frames=frs, cams=cs, race_free=True, runs=runs,
                           note="temporal on, spatial off: a-trous never runs; acc = colour_acc, var = variance/0.1, hlen = (pre-update) history length/100"))
-    frs, cs = synth_frames(pkg, 96, 96, 4, seed=22, moving=True)
+    frs, cs = synth_frames(pkg, 64, 64, 4, seed=22, moving=True)
     calls = [(1 if f == 0 else 0, f, default_params(temporal_enable=1, spatial_enable=0, color_alpha=0.05, moment_alpha=0.5)) for f in range(4)]
-    cases.append(dict(name="temporal_moving96_alphas_acc", W=96, H=96, frames=frs, cams=cs, race_free=True, calls=calls, note="other alphas"))
+    cases.append(dict(name="temporal_moving64_alphas_acc", W=64, H=64, frames=frs, cams=cs, race_free=True, calls=calls, note="other alphas"))
 
     # D. full SVGF sequences (temporal + spatial): raced in the reference after frame 0
-    for (nm, W, H, moving, hl) in (("static96", 96, 96, False, 1), ("moving96", 96, 96, True, 1), ("static128x72", 128, 72, False, 1),
-                                   ("moving96_h0", 96, 96, True, 0), ("moving96_h5", 96, 96, True, 5)):
+    for (nm, W, H, moving) in (("static64", 64, 64, False), ("moving80", 80, 80, True), ("static96x54", 96, 54, False)):
         frs, cs = synth_frames(pkg, W, H, 4, seed=31, moving=moving)
-        calls = [(1 if f == 0 else 0, f, default_params(temporal_enable=1, spatial_enable=1, history_level=hl)) for f in range(4)]
-        cases.append(dict(name=f"full_{nm}", W=W, H=H, frames=frs, cams=cs, race_free=False, calls=calls,
-                          note="frames >= 1 depend on the reference's variance race"))
+        runs = {}
+        for hl in ((1, 0, 5) if nm == "moving80" else (1,)):
+            runs[f"h{hl}"] = [(1 if f == 0 else 0, f, default_params(temporal_enable=1, spatial_enable=1, history_level=hl)) for f in range(4)]
+        cases.append(dict(name=f"full_{nm}", W=W, H=H, frames=frs, cams=cs, race_free=False, runs=runs,
+                          note="temporal + 5 a-trous levels; hK = history_level K; frames >= 1 depend on the reference's variance race"))
     # mode switches mid-sequence: off, on, on, off, on
-    frs, cs = synth_frames(pkg, 96, 96, 5, seed=41, moving=False)
+    frs, cs = synth_frames(pkg, 64, 64, 5, seed=41, moving=False)
     modes = [0, 1, 1, 0, 1]
     calls = [(1 if f == 0 else 0, f, default_params(temporal_enable=modes[f], spatial_enable=0)) for f in range(5)]
-    cases.append(dict(name="temporal_switch96_acc", W=96, H=96, frames=frs, cams=cs, race_free=True, calls=calls,
+    cases.append(dict(name="temporal_switch64_acc", W=64, H=64, frames=frs, cams=cs, race_free=True, calls=calls,
                       note="temporal toggled between frames, spatial off"))
     return cases
 
@@ -212,10 +211,15 @@ def main():
             outs, ms = run_reference(W, H, calls, cs["frames"], work)
             outs2, _ = run_reference(W, H, calls, cs["frames"], work)   # is the reference deterministic here?
             rerun = summarize(outs2, outs)
+            outs_nf, _ = run_reference(W, H, calls, cs["frames"], work, binary=REF_BIN_NOFMA)
             arrays[f"call_reset_{tag}"] = np.array([c[0] for c in rcalls], dtype=np.int32)
             arrays[f"call_frame_{tag}"] = np.array([c[1] for c in rcalls], dtype=np.int32)
             arrays[f"call_params_{tag}"] = np.array([[float(c[2][k]) for k in PARAM_KEYS] for c in rcalls], dtype="<f8")
-            arrays[f"ref_out_{tag}"] = outs.astype("<f4")
+            # primary golden: the -ffp-contract=off build (arithmetic exactly as the reference source states it).
+            # The default-flags build (FMA contraction on) is kept for a subset, to bound what contraction changes.
+            arrays[f"ref_nofma_out_{tag}"] = outs_nf.astype("<f4")
+            if cs["name"] in KEEP_DEFAULT_BUILD:
+                arrays[f"ref_out_{tag}"] = outs.astype("<f4")
             entry = dict(W=W, H=H, ncalls=len(calls), race_free=cs["race_free"], ref_rerun=rerun)
             if a.compare:
                 P = pkg.SvgfParams
@@ -231,13 +235,16 @@ def main():
                 o.free(); d.free()
                 o_out = np.stack(o_out); d_out = np.stack(d_out)
                 entry["oracle_vs_ref"] = summarize(o_out, outs)
+                entry["oracle_vs_ref_nofma"] = summarize(o_out, outs_nf)
+                entry["hip_vs_ref_nofma"] = summarize(d_out, outs_nf)
                 entry["hip_vs_ref"] = summarize(d_out, outs)
                 entry["hip_vs_oracle"] = summarize(d_out, o_out)
                 entry["per_call_oracle_vs_ref_fracgt1e4"] = [summarize(o_out[i], outs[i])["frac_gt_1e4"] for i in range(len(calls))]
             report[cs["name"] + ":" + tag] = entry
             line = f"{cs['name'] + ':' + tag:40s} rerun max {rerun['max']:.1e}"
             if a.compare:
-                line += (f" | oracle-ref max {entry['oracle_vs_ref']['max']:.1e} >1e-4 {entry['oracle_vs_ref']['frac_gt_1e4']:.4f}"
+                line += (f" | oracle-refNOFMA max {entry['oracle_vs_ref_nofma']['max']:.1e} >1e-4 {entry['oracle_vs_ref_nofma']['frac_gt_1e4']:.4f}"
+                         f" | oracle-ref max {entry['oracle_vs_ref']['max']:.1e} >1e-4 {entry['oracle_vs_ref']['frac_gt_1e4']:.4f}"
                          f" | hip-ref max {entry['hip_vs_ref']['max']:.1e} >1e-4 {entry['hip_vs_ref']['frac_gt_1e4']:.4f}"
                          f" | hip-oracle max {entry['hip_vs_oracle']['max']:.1e}")
             print(line, flush=True)

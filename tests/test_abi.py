@@ -1,0 +1,74 @@
+"""The C-ABI library builds for gfx950, loads on a CPU-only host and exports every symbol include/svgf.h declares.
+No compute is issued here (there is no GPU in the build container)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from conftest import ROOT
+
+
+def header_functions():
+    src = open(os.path.join(ROOT, "include", "svgf.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(svgf_[a-z_]+)\s*\(", src)))
+
+
+def test_header_symbols_exported(pkg):
+    lib = ctypes.CDLL(pkg.binding.LIB_PATH)
+    names = header_functions()
+    assert len(names) >= 16
+    for n in names:
+        assert hasattr(lib, n), f"libsvgf_hip.so does not export {n}"
+    assert sorted(pkg.binding.EXPORTS) == names
+
+
+def test_struct_layouts_match_reference(pkg):
+    # GBufferTexel: 52 B, align 4, offsets 0/12/24/36/48 (reference src/sceneStructs.h:113-119)
+    dt = pkg.synth.GBUFFER_DTYPE
+    assert dt.itemsize == 52
+    assert [dt.fields[k][1] for k in ("normal", "position", "albedo", "ialbedo", "geomId")] == [0, 12, 24, 36, 48]
+    assert ctypes.sizeof(pkg.SvgfCamera) == 48
+    assert ctypes.sizeof(pkg.SvgfParams) == 17 * 4
+
+
+def test_params_default_matches_reference_ui_defaults(pkg):
+    lib = pkg.load_library()
+    p = pkg.SvgfParams()
+    assert lib.svgf_params_default(ctypes.byref(p)) == 0
+    q = pkg.reference_defaults()        # reference src/main.cpp:49-62
+    for name, _ in pkg.SvgfParams._fields_[:14]:
+        assert getattr(p, name) == pytest.approx(getattr(q, name)), name
+    assert lib.svgf_version() == (0 << 16) | 1
+
+
+def test_error_paths_without_gpu(pkg):
+    import torch
+    lib = pkg.load_library()
+    h = ctypes.c_void_p()
+    assert lib.svgf_create(0, 0, 10, ctypes.byref(h)) == -1            # SVGF_ERR_INVALID_ARG
+    assert lib.svgf_create(0, 16, 16, None) == -1
+    assert lib.svgf_destroy(None) == 0                                 # denoiseFree on NULL is harmless
+    assert lib.svgf_reset(None) == -1
+    if not torch.cuda.is_available():
+        rc = lib.svgf_create(0, 16, 16, ctypes.byref(h))
+        assert rc == -2, "without a GPU the library must fail loudly (SVGF_ERR_NO_DEVICE), not fall back"
+        assert b"no usable HIP device" in lib.svgf_last_error(None)
+        with pytest.raises(pkg.SvgfError):
+            pkg.Denoiser(16, 16)
+
+
+def test_product_never_touches_the_oracle():
+    """The shipped path must not import/link/execute anything under oracle/."""
+    pk = os.path.join(ROOT, "cuda-path-tracer-denoising_amd")
+    for dirpath, _, files in os.walk(pk):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                text = open(os.path.join(dirpath, f)).read()
+                if f == "build.py":      # builds the checker; building is not using
+                    continue
+                assert "svgf_oracle" not in text and "oracle_py" not in text, os.path.join(dirpath, f)
+    import subprocess
+    out = subprocess.run(["ldd", os.path.join(pk, "libsvgf_hip.so")], stdout=subprocess.PIPE, text=True).stdout
+    assert "oracle" not in out

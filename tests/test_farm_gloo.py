@@ -1,0 +1,68 @@
+"""world_size-2 gloo run of the N>1 path: sequence sharding, barrier-bracketed timing, MAX time / SUM work reduce.
+The per-rank 'GPU work' is replaced by the CPU oracle on tiny frames (no GPU in this container)."""
+import os
+import sys
+
+import numpy as np
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    import __graft_entry__ as ge
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    pkg = ge.load_package()
+    orc = ge.load_oracle()
+    W, H, nseq = 24, 16, 5
+    mine = pkg.farm.shard(nseq, world, rank)
+    engines = {s: orc.Oracle(pkg, W, H) for s in mine}
+    frames = {s: pkg.synth.render_frame(W, H, 0, seed=100 + s) for s in mine}
+    p = pkg.reference_defaults().set(temporal_enable=1, spatial_enable=1, atrous_nlevel=2)
+    checks = {}
+
+    def step(i):
+        px = 0
+        for s in mine:
+            out = engines[s].denoise(*frames[s], p)
+            checks[s] = float(out.sum())
+            px += W * H
+        return px
+
+    dt, units = pkg.farm.timed_region(step, steps=3, warmup=1, sync_fn=lambda: None, dist=dist)
+    q.put((rank, mine, dt, units, checks))
+    dist.destroy_process_group()
+
+
+def test_two_rank_farm():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    res.sort()
+    assert sorted(res[0][1] + res[1][1]) == [0, 1, 2, 3, 4]          # every sequence owned once
+    assert res[0][2] == res[1][2] > 0                                 # both ranks report the MAX time
+    assert res[0][3] == res[1][3] == 3 * 5 * 24 * 16                  # SUM of work over ranks = all sequences x steps
+    # a sequence gives the same result whichever rank runs it
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as ge
+    pkg = ge.load_package(); orc = ge.load_oracle()
+    p = pkg.reference_defaults().set(temporal_enable=1, spatial_enable=1, atrous_nlevel=2)
+    for (_, mine, _, _, checks) in res:
+        for s in mine:
+            o = orc.Oracle(pkg, 24, 16)
+            fr = pkg.synth.render_frame(24, 16, 0, seed=100 + s)
+            for _ in range(4):
+                out = o.denoise(*fr, p)
+            o.free()
+            assert np.isclose(float(out.sum()), checks[s], rtol=0, atol=0)

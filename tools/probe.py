@@ -1,0 +1,91 @@
+#!/usr/bin/env python3
+"""Developer probe (GPU box): per-kernel timings of the HIP path at a given size, strip vs gather kernel,
+plus the strip kernel's deviation from the strict gather kernel on the same frames.
+
+  python tools/probe.py --size 1920x1080 --frames 12 [--variants 1,2] [--env SVGF_STRIP_TX=256,SVGF_STRIP_ROWS=1]
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as ge  # noqa: E402
+
+KIND = {1: "temporal", 2: "prepare", 3: "atrous", 4: "debug", 5: "copyout"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--size", default="1920x1080")
+    ap.add_argument("--frames", type=int, default=12)
+    ap.add_argument("--variants", default="1,2")
+    ap.add_argument("--nlevel", type=int, default=5)
+    ap.add_argument("--check", action="store_true", help="compare outputs of the variants frame by frame")
+    a = ap.parse_args()
+    import torch
+    pkg = ge.load_package()
+    W, H = map(int, a.size.split("x"))
+    n = W * H
+    nsrc = 2
+    frames = [pkg.synth.render_frame(W, H, f, seed=5, moving=False) for f in range(nsrc)]
+    d_in = [torch.from_numpy(f[0]).cuda() for f in frames]
+    d_g = [torch.from_numpy(f[1].view(np.uint8).reshape(-1)).cuda() for f in frames]
+    cam = [pkg.SvgfCamera.from_dict(f[2]) for f in frames]
+    out = torch.empty((H, W, 3), dtype=torch.float32, device="cuda")
+    results = {}
+    for v in [int(x) for x in a.variants.split(",")]:
+        d = pkg.Denoiser(W, H, 0)
+        p = pkg.reference_defaults().set(temporal_enable=1, spatial_enable=1, atrous_nlevel=a.nlevel, kernel_variant=v)
+        d.profile_enable(a.frames)
+        outs = []
+        for f in range(a.frames):
+            d.denoise(out, d_in[f % nsrc], d_g[f % nsrc], cam[f % nsrc], p)
+            if a.check:
+                torch.cuda.synchronize()
+                outs.append(out.cpu().numpy().copy())
+        d.sync()
+        # whole-frame wall time without per-kernel events
+        d.profile_enable(0)
+        torch.cuda.synchronize()
+        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        reps = 20
+        for f in range(reps):
+            d.denoise(out, d_in[f % nsrc], d_g[f % nsrc], cam[f % nsrc], p)
+        e1.record(); torch.cuda.synchronize()
+        frame_ms = e0.elapsed_time(e1) / reps
+        d.profile_enable(a.frames)
+        for f in range(a.frames):
+            d.denoise(out, d_in[f % nsrc], d_g[f % nsrc], cam[f % nsrc], p)
+        d.sync()
+        rows = [d.profile_read(s) for s in range(a.frames)]
+        steady = rows[2:]
+        nk = len(steady[0])
+        med = [float(np.median([r[k][1] for r in steady])) for k in range(nk)]
+        kinds = [steady[0][k][0] for k in range(nk)]
+        print(f"variant {v}: frame wall {frame_ms*1e3:.1f} us = {n/frame_ms/1e3:.1f} Mpix/s ; sum of kernels {sum(med)*1e3:.1f} us")
+        lvl = 0
+        for k in range(nk):
+            name = KIND[kinds[k]]
+            extra = ""
+            if kinds[k] == 3:
+                lvl += 1
+                gbs = 56.0 * n / (med[k] * 1e-3) / 1e9
+                extra = f" step {1 << lvl:3d}  {gbs:7.0f} GB/s algorithmic ({gbs/8000*100:.1f}% of 8 TB/s)"
+            print(f"   {name:9s} {med[k]*1e3:8.1f} us{extra}")
+        results[v] = outs
+        d.free()
+    if a.check and len(results) == 2:
+        (va, oa), (vb, ob) = results.items()
+        for f in range(len(oa)):
+            e = np.abs(oa[f] - ob[f]) / np.maximum(np.abs(oa[f]), 1e-2)
+            print(f"frame {f}: variant {vb} vs {va}: max rel {e.max():.2e} p99.9 {np.quantile(e, 0.999):.2e} frac>1e-4 {(e > 1e-4).mean():.2e}")
+
+
+if __name__ == "__main__":
+    main()
