@@ -11,24 +11,38 @@
 // the same kernel serves S = 2 .. 32 where a square tile + halo could not (a 64x64 tile at S = 32 needs a 192x192
 // halo tile = 1.7 MB of LDS; SURVEY.md §7 hard parts).
 //
+// Wave specialisation.  Measured on MI355X (profiles/r01_strip_phase_timeline.log): with every wave doing
+// load -> math -> store -> barrier in lockstep, the 25-tap math ran VALU-saturated but only ~45 % of the time; the
+// rest was vector-memory issue, LDS staging and barrier skew that nothing overlapped.  The workgroup is therefore
+// TX*ROWS compute threads + two loader groups (2 waves each) that alternate iterations: a loader fetches the next ROWS lattice rows (and the two
+// full-resolution neighbour rows the 3x3 variance pre-blur needs) while the compute waves evaluate taps, converts
+// them to the LDS layout and publishes them at the single barrier that ends the iteration.  Compute waves issue no
+// vector-memory loads at all.
+//
 // LDS layout: array-of-pixels, 48 B per pixel = three 16-B slots
-//     A = {n.x, p.x, n.y, p.y}   B = {n.z, p.z, luminance, variance}   C = {r, g, b, -}
-// read with ds_read_b128.  The 48-B pixel stride is conflict-free for b128: a 16-lane group covers byte offsets
-// 48*l, i.e. 12*l dwords mod 64 = 16 distinct 4-bank slots.
-// Out-of-image pixels are staged with luminance = +inf, which makes their weight exp2(-inf) = 0 with no per-tap
-// bounds test (the reference skips those taps, :134).
+//     A = {n.x, p.x, n.y, p.y}   B = {n.z, p.z, luminance, -}   C = {r, g, b, variance}
+// read with ds_read_b128; the (normal, position) component pairs and the (r,g) / (b,variance) pairs sit in adjacent
+// registers so the per-tap arithmetic is written directly as packed fp32 (v_pk_add/mul/fma_f32) with no shuffling.
+// The 48-B pixel stride is conflict-free for b128: a 16-lane group covers byte offsets 48*l, i.e. 12*l dwords mod 64
+// = 16 distinct 4-bank slots.  Out-of-image pixels are staged with luminance = +inf, which makes their weight
+// exp2(-inf) = 0 with no per-tap bounds test (the reference skips those taps, :134).
 //
 // Arithmetic (fast path): the reference's three edge-stopping factors exp(-a)*min(1,exp(-b))*min(1,exp(-c)) with
-// a,b,c >= 0 equal exp(-(a+b+c)); it is evaluated as one v_exp_f32 of a base-2 exponent.  Non-finite
-// normals/positions make the reference's min(1, exp(NaN)) return 1 (fminf semantics); a workgroup that stages such a
-// texel switches to the `CAREFUL` tap routine that reproduces this, so ordinary frames pay nothing for it.
+// a,b,c >= 0 equal exp(-(a+b+c)); it is evaluated as one v_exp_f32 of a base-2 exponent with the filter weight h
+// folded in.  Non-finite normals/positions make the reference's min(1, exp(NaN)) return 1 (fminf
+// semantics); a workgroup that stages such a texel switches to the `CAREFUL` tap routine that reproduces this, so
+// ordinary frames pay nothing for it.
 #include "svgf_kernels.h"
 
+#include <cstdio>
 #include <cstdlib>
+#include <type_traits>
 
 namespace {
 
 constexpr float kLog2e = 1.44269504088896340736f;
+constexpr int kLoaderGroup = 128;                 // threads per loader group (two waves)
+constexpr int kLoaderThreads = 2 * kLoaderGroup;  // two groups alternate iterations
 
 struct StripGeom {
     int n_strips;   // strips of TX columns
@@ -36,6 +50,8 @@ struct StripGeom {
     int seg_rows;   // lattice rows per segment
     int n_groups;   // S * n_segs
     float kn, kx;   // log2(e) / (sigma_n + 1e-6), log2(e) / (sigma_x + 1e-6)
+    unsigned long long *dbg;   // tuning only (SVGF_STRIP_DBG): per-phase s_memtime stamps of one workgroup
+    int dbg_block;
 };
 
 struct Px {   // one staged pixel in registers
@@ -57,46 +73,71 @@ __device__ __forceinline__ bool finite3(float a, float b, float c)
     return (fabsf(a) < inf) && (fabsf(b) < inf) && (fabsf(c) < inf);
 }
 
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+struct Centre {          // per output pixel, loop invariant over the 25 taps
+    v2f nx_px, ny_py, nz_pz;
+    float lp, kl, kn, kx;
+};
+struct Acc {
+    v2f rg;              // sum w*r, sum w*g
+    v2f bv;              // sum w*b, sum w^2*variance
+    v2f ww;              // sum w,   sum w^2
+};
+
+// One tap: 3 x ds_read_b128, then 9 packed + 5 scalar VALU, 2 v_sqrt + 1 v_exp.
+//   neg_log2_h = -log2(h[k]) is folded into the exponent: h*2^-e == 2^-(e - log2 h).
 template <bool CAREFUL>
-__device__ __forceinline__ void tap(const char *lds_px, float h, float lp, float kl, float kn, float kx,
-                                    float npx, float npy, float npz, float ppx, float ppy, float ppz,
-                                    float &c0, float &c1, float &c2, float &vsum, float &wsum, float &w2sum)
+__device__ __forceinline__ void tap(const char *lds_px, float neg_log2_h, const Centre &c, Acc &acc)
 {
-    const float4 A = *reinterpret_cast<const float4 *>(lds_px);
-    const float4 B = *reinterpret_cast<const float4 *>(lds_px + 16);
-    const float4 C = *reinterpret_cast<const float4 *>(lds_px + 32);
-    const float dnx = A.x - npx, dny = A.z - npy, dnz = B.x - npz;
-    const float dpx = A.y - ppx, dpy = A.w - ppy, dpz = B.y - ppz;
-    float dn = __builtin_amdgcn_sqrtf(dnx * dnx + dny * dny + dnz * dnz);
-    float dx = __builtin_amdgcn_sqrtf(dpx * dpx + dpy * dpy + dpz * dpz);
+    const v4f A = *reinterpret_cast<const v4f *>(lds_px);
+    const v4f B = *reinterpret_cast<const v4f *>(lds_px + 16);
+    const v4f C = *reinterpret_cast<const v4f *>(lds_px + 32);
+    const v2f d0 = A.xy - c.nx_px, d1 = A.zw - c.ny_py, d2 = B.xy - c.nz_pz;
+    v2f s = d0 * d0;
+    s = __builtin_elementwise_fma(d1, d1, s);
+    s = __builtin_elementwise_fma(d2, d2, s);                  // (|dn|^2, |dp|^2)
+    float dn = __builtin_amdgcn_sqrtf(s.x);
+    float dx = __builtin_amdgcn_sqrtf(s.y);
     if (CAREFUL) {          // min(1, exp(-NaN)) == 1 in the reference: a NaN distance contributes nothing
         dn = fmaxf(dn, 0.0f);
         dx = fmaxf(dx, 0.0f);
     }
-    float e = fabsf(B.z - lp) * kl;
-    e = fmaf(dn, kn, e);
-    e = fmaf(dx, kx, e);
-    const float w = h * __builtin_amdgcn_exp2f(-e);
-    const float w2 = w * w;
-    wsum += w;
-    w2sum += w2;
-    c0 = fmaf(C.x, w, c0);
-    c1 = fmaf(C.y, w, c1);
-    c2 = fmaf(C.z, w, c2);
-    vsum = fmaf(B.w, w2, vsum);
+    float e = fmaf(fabsf(B.z - c.lp), c.kl, neg_log2_h);
+    e = fmaf(dn, c.kn, e);
+    e = fmaf(dx, c.kx, e);
+    const float w = __builtin_amdgcn_exp2f(-e);
+    v2f wv;
+    wv.x = w;
+    wv.y = w * w;
+    acc.ww += wv;
+    acc.rg = __builtin_elementwise_fma(C.xy, v2f{w, w}, acc.rg);
+    acc.bv = __builtin_elementwise_fma(C.zw, wv, acc.bv);
+}
+
+// -log2 of the 5-tap binomial [1 4 6 4 1]/16 (log2(6/16) is the only inexact one)
+__device__ __forceinline__ constexpr float neg_log2_binom(int i)
+{
+    return (i == 0) ? 1.4150374992788437f : ((i == 1 || i == -1) ? 2.0f : 4.0f);
 }
 
 template <int LOG2S, int TX, int ROWS>
-__global__ __launch_bounds__(TX * ROWS) void k_atrous_strip(AtrousArgs a, StripGeom gm)
+__global__ __launch_bounds__(TX * ROWS + kLoaderThreads) void k_atrous_strip(AtrousArgs a, StripGeom gm)
 {
     constexpr int S = 1 << LOG2S;
     constexpr int RW = TX + 4 * S;          // staged pixels per lattice row
     constexpr int R = 4 + 2 * ROWS;         // ring slots: 4 + ROWS live, ROWS incoming
-    constexpr int PPT = (RW + TX - 1) / TX; // staged pixels per thread per row
     constexpr int PXB = 48;                 // bytes per staged pixel
+    constexpr int NC = TX * ROWS;           // compute threads
+    constexpr int NT = NC + kLoaderThreads; // + the loader waves
+    constexpr int BW = TX + 2;              // blur row: columns x0-1 .. x0+TX
+    constexpr int RING_BYTES = R * RW * PXB;
+    constexpr int BLUR_FLOATS = 2 * ROWS * 2 * BW;   // [iteration parity][row of iteration][y-1 | y+1][BW]
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    int *nan_seen = reinterpret_cast<int *>(smem + (size_t)R * RW * PXB);
+    float *blur = reinterpret_cast<float *>(smem + RING_BYTES);
+    int *nan_seen = reinterpret_cast<int *>(smem + RING_BYTES + BLUR_FLOATS * 4);
 
     // ---- work item: (strip, y-phase, segment); all strips of one (phase, segment) share an XCD's L2 ----
     const int bid = blockIdx.x;
@@ -114,168 +155,220 @@ __global__ __launch_bounds__(TX * ROWS) void k_atrous_strip(AtrousArgs a, StripG
     const int x0 = strip * TX;
 
     const int tid = threadIdx.x;
-    const int r = tid / TX;                 // which of the ROWS rows of an iteration this thread serves
-    const int tx = tid - r * TX;
 
     if (tid == 0) *nan_seen = 0;
 
     auto slot_of = [&](int br) { return (br - (b0 - 2)) % R; };   // br >= b0-2 always
 
-    // global -> registers for lattice row br, pixels tx + k*TX
-    auto stage_load = [&](int br, Px(&px)[PPT]) {
-        const int y = phase + (br << LOG2S);
-        const bool row_ok = (br >= 0) && (y < H);
+    // ---- staging, split in two halves so that a batch of loads can stay in flight across a barrier ----
+    // rows_load : global -> registers for lattice rows br_first .. br_first+nrows-1, pixels wi, wi+nw, ...
+    // rows_store: registers -> LDS ring (layout conversion, luminance, non-finite detection)
+    auto rows_load = [&](auto &px, int br_first, int nrows, int wi, int nw) {
+        constexpr int M = sizeof(px) / sizeof(px[0]);
 #pragma unroll
-        for (int kk = 0; kk < PPT; kk++) {
-            const int xi = tx + kk * TX;
-            const int xs = x0 - 2 * S + xi;
-            px[kk].valid = row_ok && (xi < RW) && (xs >= 0) && (xs < W);
-            if (px[kk].valid) {
-                const size_t q = (size_t)y * W + xs;
-                px[kk].cv = a.src[q];
-                const float *n = a.nrm + 3 * q;
-                const float *p = a.pos + 3 * q;
-                px[kk].nx = n[0]; px[kk].ny = n[1]; px[kk].nz = n[2];
-                px[kk].px = p[0]; px[kk].py = p[1]; px[kk].pz = p[2];
+        for (int m = 0; m < M; m++) {
+            const int idx = wi + m * nw;
+            px[m].valid = false;
+            if (idx < nrows * RW) {
+                const int rr = idx / RW, xi = idx - rr * RW;
+                const int br = br_first + rr;
+                const int y = phase + (br << LOG2S);
+                const int xs = x0 - 2 * S + xi;
+                px[m].valid = (br >= 0) && (y < H) && (xs >= 0) && (xs < W);
+                if (px[m].valid) {
+                    const unsigned q = (unsigned)y * (unsigned)W + (unsigned)xs;   // < 2^28 (checked on the host)
+                    px[m].cv = a.src[q];
+                    const float *n = a.nrm + 3u * q;
+                    const float *p = a.pos + 3u * q;
+                    px[m].nx = n[0]; px[m].ny = n[1]; px[m].nz = n[2];
+                    px[m].px = p[0]; px[m].py = p[1]; px[m].pz = p[2];
+                }
             }
         }
     };
-    // registers -> LDS ring slot
-    auto stage_store = [&](int br, const Px(&px)[PPT]) {
-        char *rowbase = smem + (size_t)slot_of(br) * RW * PXB;
+    auto rows_store = [&](const auto &px, int br_first, int nrows, int wi, int nw) {
+        constexpr int M = sizeof(px) / sizeof(px[0]);
 #pragma unroll
-        for (int kk = 0; kk < PPT; kk++) {
-            const int xi = tx + kk * TX;
-            if (xi < RW) {
+        for (int m = 0; m < M; m++) {
+            const int idx = wi + m * nw;
+            if (idx < nrows * RW) {
+                const int rr = idx / RW, xi = idx - rr * RW;
                 float4 A, B, C;
-                if (px[kk].valid) {
-                    A = make_float4(px[kk].nx, px[kk].px, px[kk].ny, px[kk].py);
-                    B = make_float4(px[kk].nz, px[kk].pz, lum_f64(px[kk].cv.x, px[kk].cv.y, px[kk].cv.z), px[kk].cv.w);
-                    C = make_float4(px[kk].cv.x, px[kk].cv.y, px[kk].cv.z, 0.0f);
-                    if (!finite3(px[kk].nx, px[kk].ny, px[kk].nz) || !finite3(px[kk].px, px[kk].py, px[kk].pz)) *nan_seen = 1;
+                if (px[m].valid) {
+                    A = make_float4(px[m].nx, px[m].px, px[m].ny, px[m].py);
+                    B = make_float4(px[m].nz, px[m].pz, lum_f64(px[m].cv.x, px[m].cv.y, px[m].cv.z), 0.0f);
+                    C = px[m].cv;
+                    if (!finite3(px[m].nx, px[m].ny, px[m].nz) || !finite3(px[m].px, px[m].py, px[m].pz)) *nan_seen = 1;
                 } else {
                     A = make_float4(0.f, 0.f, 0.f, 0.f);
                     B = make_float4(0.f, 0.f, __builtin_huge_valf(), 0.f);   // luminance = +inf => weight 0
                     C = make_float4(0.f, 0.f, 0.f, 0.f);
                 }
-                char *d = rowbase + (size_t)xi * PXB;
+                char *d = smem + ((size_t)slot_of(br_first + rr) * RW + xi) * PXB;
                 *reinterpret_cast<float4 *>(d) = A;
                 *reinterpret_cast<float4 *>(d + 16) = B;
                 *reinterpret_cast<float4 *>(d + 32) = C;
             }
         }
     };
-
-    // variance of the two full-resolution neighbour rows (y-1, y+1) of output row bo, columns x-1..x+1, for the
-    // 3x3 pre-blur (:102-118).  Own column per lane; the wave's edge lanes fetch their outer neighbour too.
-    struct BlurPre { float vm, vp, em, ep; };
-    const int lane = tid & 63;
-    auto blur_load = [&](int bo, BlurPre &bp) {
-        bp.vm = bp.vp = bp.em = bp.ep = 0.0f;
-        const int x = x0 + tx;
-        const int y = phase + (bo << LOG2S);
-        if (!a.blur_variance || bo >= b1 || x >= W) return;
-        const int xe = (lane == 0) ? x - 1 : x + 1;                       // edge lanes' extra column
-        const bool edge = (lane == 0 || lane == 63) && xe >= 0 && xe < W;
-        if (y - 1 >= 0) {
-            bp.vm = a.src[(size_t)(y - 1) * W + x].w;
-            if (edge) bp.em = a.src[(size_t)(y - 1) * W + xe].w;
+    // variance of the full-resolution rows y-1 and y+1 of output rows bo_first .. +ROWS-1 (3x3 pre-blur, :102-118)
+    auto blur_load = [&](auto &v, int bo_first, int wi, int nw) {
+        constexpr int M = sizeof(v) / sizeof(v[0]);
+#pragma unroll
+        for (int m = 0; m < M; m++) {
+            const int idx = wi + m * nw;
+            v[m] = 0.0f;
+            if (a.blur_variance && idx < ROWS * 2 * BW) {
+                const int rr = idx / (2 * BW), rem = idx - rr * (2 * BW);
+                const int d = rem / BW, xi = rem - d * BW;
+                const int y = phase + ((bo_first + rr) << LOG2S) + (d ? 1 : -1);
+                const int xs = x0 - 1 + xi;
+                if (y >= 0 && y < H && xs >= 0 && xs < W && bo_first + rr < b1) v[m] = a.src[(unsigned)y * (unsigned)W + (unsigned)xs].w;
+            }
         }
-        if (y + 1 < H) {
-            bp.vp = a.src[(size_t)(y + 1) * W + x].w;
-            if (edge) bp.ep = a.src[(size_t)(y + 1) * W + xe].w;
+    };
+    auto blur_store = [&](const auto &v, int parity, int wi, int nw) {
+        constexpr int M = sizeof(v) / sizeof(v[0]);
+#pragma unroll
+        for (int m = 0; m < M; m++) {
+            const int idx = wi + m * nw;
+            if (idx < ROWS * 2 * BW) blur[parity * (ROWS * 2 * BW) + idx] = v[m];
         }
     };
 
-    // ---- prologue: rows b0-2 .. b0+ROWS+1 into the ring ----
-    {
-        Px px[PPT];
-        for (int rr = 0; rr < 4 + ROWS; rr += ROWS) {
-            const int br = b0 - 2 + rr + r;
-            if (rr + r < 4 + ROWS) {
-                stage_load(br, px);
-                stage_store(br, px);
-            }
+    // Loader groups: two groups of kLoaderGroup threads; group q owns the rows that iterations j with (j & 1) == q
+    // newly need.  A group issues its loads at the start of iteration j-2, keeps them in flight across that
+    // iteration's barrier, converts and stores them during iteration j-1, and the barrier ending j-1 publishes them:
+    // every global load has a whole iteration (~2-3 us) to land, and each group only works every other iteration.
+    constexpr int ML = (ROWS * RW + kLoaderGroup - 1) / kLoaderGroup;
+    constexpr int MBL = (ROWS * 2 * BW + kLoaderGroup - 1) / kLoaderGroup;
+    const bool is_loader = (tid >= NC);
+    const int lgroup = is_loader ? (tid - NC) / kLoaderGroup : -1;
+    const int llane = is_loader ? (tid - NC) % kLoaderGroup : 0;
+    Px lpx[ML];
+    float lbv[MBL];
+    // new rows of iteration j: lattice rows b0 + j*ROWS + 2 .. +ROWS-1 (+ROWS); its output rows start at b0 + j*ROWS
+    auto loader_issue = [&](int j) {
+        const int bcj = b0 + j * ROWS;
+        if (bcj < b1) {
+            rows_load(lpx, bcj + 2, ROWS, llane, kLoaderGroup);
+            blur_load(lbv, bcj, llane, kLoaderGroup);
         }
+    };
+    auto loader_commit = [&](int j) {
+        const int bcj = b0 + j * ROWS;
+        if (bcj < b1) {
+            rows_store(lpx, bcj + 2, ROWS, llane, kLoaderGroup);
+            if (a.blur_variance) blur_store(lbv, j & 1, llane, kLoaderGroup);
+        }
+    };
+
+    // ---- prologue: every thread helps stage rows b0-2 .. b0+ROWS+1 and the blur rows of iteration 0;
+    //      loader group 1 also puts the loads of iteration 1 in flight ----
+    {
+        constexpr int M = ((4 + ROWS) * RW + NT - 1) / NT;
+        Px px[M];
+        rows_load(px, b0 - 2, 4 + ROWS, tid, NT);
+        constexpr int MB = (ROWS * 2 * BW + NT - 1) / NT;
+        float bv[MB];
+        blur_load(bv, b0, tid, NT);
+        rows_store(px, b0 - 2, 4 + ROWS, tid, NT);
+        if (a.blur_variance) blur_store(bv, 0, tid, NT);
     }
-    BlurPre bp;
-    blur_load(b0 + r, bp);
+    if (lgroup == 1) loader_issue(1);
     __syncthreads();
 
-    const float kn = gm.kn, kx = gm.kx;
+    int dbg_it = 0;
+    auto stamp = [&](int phase_id) {
+        if (gm.dbg && bid == gm.dbg_block && (tid & 63) == 0 && dbg_it < 16)
+            gm.dbg[((tid >> 6) * 16 + dbg_it) * 8 + phase_id] = __builtin_amdgcn_s_memtime();
+    };
+
+    if (is_loader) {
+        // ================================ loader waves ================================
+        __builtin_amdgcn_s_setprio(3);
+        int it = 0;
+        for (int bc = b0; bc < b1; bc += ROWS, it++, dbg_it++) {
+            stamp(0);
+            if (((it + 1) & 1) == lgroup) loader_commit(it + 1);   // loads were issued during iteration it-1
+            else loader_issue(it + 2);
+            stamp(5);
+            __syncthreads();
+            stamp(6);
+        }
+        return;
+    }
+
+    // ================================ compute waves ================================
+    const int r = tid / TX;                 // which of the ROWS rows of an iteration this thread serves
+    const int tx = tid - r * TX;
     const int x = x0 + tx;
+    const float kn = gm.kn, kx = gm.kx;
+    const char *colbase = smem + (size_t)tx * PXB;
 
-    for (int bc = b0; bc < b1; bc += ROWS) {
-        // prefetch the next ROWS lattice rows (global -> registers) and the next blur rows
-        Px nxt[PPT];
-        const int bin = bc + ROWS + 2 + r;
-        const bool more = (bc + ROWS < b1);
-        if (more) stage_load(bin, nxt);
-        BlurPre bpn;
-        if (more) blur_load(bc + ROWS + r, bpn);
-
+    int it = 0;
+    for (int bc = b0; bc < b1; bc += ROWS, it++, dbg_it++) {
+        stamp(0);
         const int bo = bc + r;
         if (bo < b1 && x < W) {
             const int y = phase + (bo << LOG2S);
-            const char *rowc = smem + (size_t)slot_of(bo) * RW * PXB + (size_t)(tx + 2 * S) * PXB;
+            const char *rowc = colbase + (size_t)slot_of(bo) * RW * PXB + (size_t)(2 * S) * PXB;
             const float4 A = *reinterpret_cast<const float4 *>(rowc);
             const float4 B = *reinterpret_cast<const float4 *>(rowc + 16);
             const float4 C = *reinterpret_cast<const float4 *>(rowc + 32);
+            const bool careful = (*nan_seen != 0);
 
-            // centre variance
-            float var = B.w;
+            // centre variance: 3x3 gaussian with out-of-image taps dropped and renormalised (:102-118)
+            float var = C.w;
             if (a.blur_variance) {
-                // row y from the ring (columns x-1, x, x+1), rows y-1 / y+1 from the prefetch + lane shuffles
-                const float v0l = *reinterpret_cast<const float *>(rowc - PXB + 28);
-                const float v0r = *reinterpret_cast<const float *>(rowc + PXB + 28);
-                const bool up = (y - 1 >= 0), dn = (y + 1 < H);
-                const float wr_m = up ? 0.25f : 0.0f, wr_p = dn ? 0.25f : 0.0f;
-                const float sv = wr_m * bp.vm + wr_p * bp.vp;             // vertical partial of own column (rows y-1,y+1)
-                float svl = __shfl_up(sv, 1), svr = __shfl_down(sv, 1);
-                const float se = wr_m * bp.em + wr_p * bp.ep;
-                if (lane == 0) svl = se;
-                if (lane == 63) svr = se;
-                const bool lf = (x - 1 >= 0), rt = (x + 1 < W);
-                const float wc_l = lf ? 0.25f : 0.0f, wc_r = rt ? 0.25f : 0.0f;
-                // full column sums (row y weight 0.5)
-                const float col_c = sv + 0.5f * B.w;
-                const float col_l = svl + 0.5f * v0l;
-                const float col_r = svr + 0.5f * v0r;
+                const float *bl = blur + (it & 1) * (ROWS * 2 * BW) + r * (2 * BW) + tx;    // column x-1 of row y-1
+                const float m0 = bl[0], m1 = bl[1], m2 = bl[2];
+                const float p0 = bl[BW], p1 = bl[BW + 1], p2 = bl[BW + 2];
+                const float c0v = *reinterpret_cast<const float *>(rowc - PXB + 44);
+                const float c2v = *reinterpret_cast<const float *>(rowc + PXB + 44);
+                const float wr_m = (y - 1 >= 0) ? 0.25f : 0.0f, wr_p = (y + 1 < H) ? 0.25f : 0.0f;
+                const float wc_l = (x - 1 >= 0) ? 0.25f : 0.0f, wc_r = (x + 1 < W) ? 0.25f : 0.0f;
+                const float col_l = wr_m * m0 + 0.5f * c0v + wr_p * p0;
+                const float col_c = wr_m * m1 + 0.5f * C.w + wr_p * p1;
+                const float col_r = wr_m * m2 + 0.5f * c2v + wr_p * p2;
                 const float sum = wc_l * col_l + 0.5f * col_c + wc_r * col_r;
                 const float sumw = (wr_m + 0.5f + wr_p) * (wc_l + 0.5f + wc_r);
-                var = sum / sumw;
+                var = sum * __builtin_amdgcn_rcpf(sumw);
             }
             var = fmaxf(var, 0.0f);
-            const float kl = kLog2e / (__builtin_amdgcn_sqrtf(var) * a.sigma_c + 1e-6f);
-            const float lp = B.z;
 
-            float c0 = 0.f, c1 = 0.f, c2 = 0.f, vsum = 0.f, wsum = 0.f, w2sum = 0.f;
-            const bool careful = (*nan_seen != 0);
-            const char *colbase = smem + (size_t)tx * PXB;
+            Centre c;
+            c.nx_px = v2f{A.x, A.y}; c.ny_py = v2f{A.z, A.w}; c.nz_pz = v2f{B.x, B.y};
+            c.lp = B.z;
+            c.kl = kLog2e * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(var) * a.sigma_c + 1e-6f);
+            c.kn = kn; c.kx = kx;
+            stamp(2);
+
+            Acc acc;
             if (!careful) {
+                // The centre tap has weight exactly h = 9/64 (all three distances are 0): no arithmetic needed.
+                constexpr float w0 = 0.140625f;
+                acc.ww = v2f{w0, w0 * w0};
+                acc.rg = v2f{w0 * C.x, w0 * C.y};
+                acc.bv = v2f{w0 * C.z, (w0 * w0) * C.w};
 #pragma unroll
                 for (int j = -2; j <= 2; j++) {
                     const char *rowp = colbase + (size_t)slot_of(bo + j) * RW * PXB;
-                    const float hj = (j == 0) ? 6.0f : ((j == 1 || j == -1) ? 4.0f : 1.0f);
 #pragma unroll
-                    for (int i = -2; i <= 2; i++) {
-                        const float hi = (i == 0) ? 6.0f : ((i == 1 || i == -1) ? 4.0f : 1.0f);
-                        tap<false>(rowp + (i + 2) * S * PXB, hi * hj * (1.0f / 256.0f), lp, kl, kn, kx,
-                                   A.x, A.z, B.x, A.y, A.w, B.y, c0, c1, c2, vsum, wsum, w2sum);
-                    }
+                    for (int i = -2; i <= 2; i++)
+                        if (i != 0 || j != 0) tap<false>(rowp + (i + 2) * S * PXB, neg_log2_binom(i) + neg_log2_binom(j), c, acc);
                 }
             } else {
+                acc.rg = v2f{0.0f, 0.0f}; acc.bv = v2f{0.0f, 0.0f}; acc.ww = v2f{0.0f, 0.0f};
                 for (int j = -2; j <= 2; j++) {
                     const char *rowp = colbase + (size_t)slot_of(bo + j) * RW * PXB;
-                    const float hj = (j == 0) ? 6.0f : ((j == 1 || j == -1) ? 4.0f : 1.0f);
 #pragma unroll
-                    for (int i = -2; i <= 2; i++) {
-                        const float hi = (i == 0) ? 6.0f : ((i == 1 || i == -1) ? 4.0f : 1.0f);
-                        tap<true>(rowp + (i + 2) * S * PXB, hi * hj * (1.0f / 256.0f), lp, kl, kn, kx,
-                                  A.x, A.z, B.x, A.y, A.w, B.y, c0, c1, c2, vsum, wsum, w2sum);
-                    }
+                    for (int i = -2; i <= 2; i++)
+                        tap<true>(rowp + (i + 2) * S * PXB, neg_log2_binom(i) + neg_log2_binom(j), c, acc);
                 }
             }
+            stamp(3);
+            const float c0 = acc.rg.x, c1 = acc.rg.y, c2 = acc.bv.x, vsum = acc.bv.y, wsum = acc.ww.x, w2sum = acc.ww.y;
 
             float o0, o1, o2, ov;
             if (wsum > 1e-5f) {                                     // NaN -> false -> pass-through (:159-164)
@@ -283,32 +376,27 @@ __global__ __launch_bounds__(TX * ROWS) void k_atrous_strip(AtrousArgs a, StripG
                 o0 = c0 * rw; o1 = c1 * rw; o2 = c2 * rw;
                 ov = vsum * __builtin_amdgcn_rcpf(w2sum);
             } else {
-                o0 = C.x; o1 = C.y; o2 = C.z; ov = B.w;
+                o0 = C.x; o1 = C.y; o2 = C.z; ov = C.w;
             }
-            const size_t p = (size_t)y * W + x;
+            const unsigned p = (unsigned)y * (unsigned)W + (unsigned)x;
             if (a.modulate) {                                      // last level: * albedo * ialbedo (:166-168)
-                const float *t = a.gbuf + 13 * p;
+                const float *t = a.gbuf + 13u * (size_t)p;
                 o0 *= t[6] * t[9]; o1 *= t[7] * t[10]; o2 *= t[8] * t[11];
             }
             if (a.dst) a.dst[p] = make_float4(o0, o1, o2, ov);
-            if (a.out_rgb) { float *o = a.out_rgb + 3 * p; o[0] = o0; o[1] = o1; o[2] = o2; }
+            if (a.out_rgb) { float *o = a.out_rgb + 3u * p; o[0] = o0; o[1] = o1; o[2] = o2; }
         }
-
-        // the incoming rows go to the slots that held rows bc-2 .. bc-2+ROWS-1's predecessors: slot_of(bin) is not
-        // read by this iteration (it reads rows bc-2 .. bc+ROWS+1), so no barrier is needed before the store.
-        if (more) stage_store(bin, nxt);
-        bp = bpn;
+        stamp(5);
         __syncthreads();
+        stamp(6);
     }
 }
-
-struct StripCfg { int log2s, tx, rows; };
 
 template <int LOG2S, int TX, int ROWS>
 hipError_t launch_cfg(const AtrousArgs &a, hipStream_t s)
 {
-    constexpr int S = 1 << LOG2S, RW = TX + 4 * S, R = 4 + 2 * ROWS;
-    const size_t lds = (size_t)R * RW * 48 + 16;
+    constexpr int S = 1 << LOG2S, RW = TX + 4 * S, R = 4 + 2 * ROWS, BW = TX + 2;
+    const size_t lds = (size_t)R * RW * 48 + (size_t)2 * ROWS * 2 * BW * 4 + 16;
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_atrous_strip<LOG2S, TX, ROWS>),
@@ -319,34 +407,82 @@ hipError_t launch_cfg(const AtrousArgs &a, hipStream_t s)
     StripGeom gm;
     gm.n_strips = (a.W + TX - 1) / TX;
     const int nb_max = (a.H + S - 1) / S;
-    // enough (strip, phase, segment) items to fill 256 CUs a few times over, but segments of at least 16 rows
-    int segs = 1;
-    const int target = 1024;
-    while (gm.n_strips * S * segs < target && (nb_max + segs) / (segs + 1) >= 16) segs++;
-    if (const char *e = getenv("SVGF_STRIP_SEGS")) { int v = atoi(e); if (v > 0) segs = v; }
-    gm.n_segs = segs;
-    gm.seg_rows = (nb_max + segs - 1) / segs;
-    gm.seg_rows = ((gm.seg_rows + ROWS - 1) / ROWS) * ROWS;
+    // Segment length: every (strip, phase, segment) is one workgroup, and LDS admits `bpc` workgroups per CU, so the
+    // grid runs in ceil(blocks / (CUs * bpc)) rounds of equal-length workgroups.  Pick the segment length L that
+    // minimises rounds * (L + fixed cost), the fixed cost being the 4 halo rows + the exposed prologue latency.
+    static int n_cu = 0;
+    if (!n_cu) {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) n_cu = 256;
+    }
+    int bpc = (int)((160 * 1024) / lds);
+    if (bpc > 2048 / (TX * ROWS + kLoaderThreads)) bpc = 2048 / (TX * ROWS + kLoaderThreads);
+    if (bpc < 1) bpc = 1;
+    const int capacity = n_cu * bpc;
+    int best_L = ((nb_max + ROWS - 1) / ROWS) * ROWS;
+    long best_cost = -1;
+    for (int L = ROWS * 4; L <= nb_max + ROWS; L += ROWS) {
+        const int segs_l = (nb_max + L - 1) / L;
+        const long blocks = (long)gm.n_strips * S * segs_l;
+        const long rounds = (blocks + capacity - 1) / capacity;
+        const long cost = rounds * (L + 8);
+        if (best_cost < 0 || cost < best_cost) { best_cost = cost; best_L = L; }
+    }
+    if (const char *e = getenv("SVGF_STRIP_SEGROWS")) { int v = atoi(e); if (v > 0) best_L = ((v + ROWS - 1) / ROWS) * ROWS; }
+    gm.seg_rows = best_L;
+    gm.n_segs = (nb_max + best_L - 1) / best_L;
     gm.n_groups = S * gm.n_segs;
+    gm.dbg = nullptr; gm.dbg_block = 0;
+    static unsigned long long *dbg_buf = nullptr;
+    const char *dbg_env = getenv("SVGF_STRIP_DBG");
+    if (dbg_env) {
+        if (!dbg_buf) (void)hipMalloc((void **)&dbg_buf, 16 * 16 * 8 * sizeof(unsigned long long));
+        (void)hipMemsetAsync(dbg_buf, 0, 16 * 16 * 8 * sizeof(unsigned long long), s);
+        gm.dbg = dbg_buf; gm.dbg_block = atoi(dbg_env);
+    }
     gm.kn = (float)(1.4426950408889634 / ((double)a.sigma_n + 1e-6));
     gm.kx = (float)(1.4426950408889634 / ((double)a.sigma_x + 1e-6));
     const int groups_pad = (gm.n_groups + 7) / 8 * 8;
     const int nblocks = groups_pad * gm.n_strips;
-    hipLaunchKernelGGL((k_atrous_strip<LOG2S, TX, ROWS>), dim3(nblocks), dim3(TX * ROWS), lds, s, a, gm);
+    hipLaunchKernelGGL((k_atrous_strip<LOG2S, TX, ROWS>), dim3(nblocks), dim3(TX * ROWS + kLoaderThreads), lds, s, a, gm);
+    if (dbg_env) {
+        static int prints = 0;
+        (void)hipStreamSynchronize(s);
+        unsigned long long h[16 * 16 * 8];
+        (void)hipMemcpy(h, dbg_buf, sizeof(h), hipMemcpyDeviceToHost);
+        if (prints++ < 10) {
+            const int nw = (TX * ROWS + kLoaderThreads) / 64;
+            fprintf(stderr, "[strip dbg] S=%d TX=%d ROWS=%d blocks=%d segs=%d seg_rows=%d lds=%zu waves=%d (last 4 = loaders)\n", S, TX,
+                    ROWS, nblocks, gm.n_segs, gm.seg_rows, lds, nw);
+            const int show[4] = { 0, nw - 5, nw - 4, nw - 2 };
+            for (int si = 0; si < 4; si++) {
+                const int w = show[si];
+                for (int it = 0; it < 16 && h[(w * 16 + it) * 8]; it++) {
+                    unsigned long long *t = &h[(w * 16 + it) * 8];
+                    if (w >= nw - 4)
+                        fprintf(stderr, "  loader  it %2d: t0=%6llu stage %6llu barrier %5llu\n", it, t[0] - h[0], t[5] - t[0], t[6] - t[5]);
+                    else
+                        fprintf(stderr, "  wave %2d it %2d: t0=%6llu centre %5llu taps %6llu out %5llu barrier %5llu\n", w, it, t[0] - h[0],
+                                t[2] - t[0], t[3] - t[2], t[5] - t[3], t[6] - t[5]);
+                }
+            }
+        }
+    }
     return hipGetLastError();
 }
 
 // default configuration per dilation; SVGF_STRIP_TX / SVGF_STRIP_ROWS override for tuning runs
 void pick(int log2s, int &tx, int &rows)
 {
-    static const int def_tx[6] = { 0, 128, 128, 256, 256, 256 };
-    static const int def_rows[6] = { 0, 2, 2, 2, 2, 1 };
+    static const int def_tx[6] = { 0, 256, 256, 256, 256, 256 };
+    static const int def_rows[6] = { 0, 2, 2, 2, 2, 2 };
     tx = def_tx[log2s]; rows = def_rows[log2s];
-    if (const char *e = getenv("SVGF_STRIP_TX")) { int v = atoi(e); if (v == 64 || v == 128 || v == 256) tx = v; }
+    if (const char *e = getenv("SVGF_STRIP_TX")) { int v = atoi(e); if (v == 128 || v == 256) tx = v; }
     if (const char *e = getenv("SVGF_STRIP_ROWS")) { int v = atoi(e); if (v == 1 || v == 2) rows = v; }
-    // LDS budget: (4 + 2*rows) * (tx + 4S) * 48 + 16 <= 160 KiB
+    // LDS budget: ring + blur rows <= 160 KiB
     const int S = 1 << log2s;
-    while ((size_t)(4 + 2 * rows) * (tx + 4 * S) * 48 + 16 > 160 * 1024 && rows > 1) rows--;
+    while ((size_t)(4 + 2 * rows) * (tx + 4 * S) * 48 + (size_t)2 * rows * 2 * (tx + 2) * 4 + 16 > 160 * 1024 && rows > 1) rows--;
 }
 
 }  // namespace
@@ -354,7 +490,7 @@ void pick(int log2s, int &tx, int &rows)
 bool atrous_strip_supported(const AtrousArgs &a)
 {
     if (a.step < 2 || a.step > 32 || (a.step & (a.step - 1))) return false;
-    if ((long long)a.W * a.H >= (1LL << 31)) return false;
+    if ((long long)a.W * a.H * 16 >= (1LL << 32)) return false;   // 32-bit element offsets in the kernel
     return true;
 }
 
@@ -366,10 +502,10 @@ hipError_t launch_atrous_strip(const AtrousArgs &a, hipStream_t s)
     while ((1 << log2s) < a.step) log2s++;
     int tx, rows;
     pick(log2s, tx, rows);
-    STRIP_CASE(1, 64, 1) STRIP_CASE(1, 64, 2) STRIP_CASE(1, 128, 1) STRIP_CASE(1, 128, 2) STRIP_CASE(1, 256, 1) STRIP_CASE(1, 256, 2)
-    STRIP_CASE(2, 64, 1) STRIP_CASE(2, 64, 2) STRIP_CASE(2, 128, 1) STRIP_CASE(2, 128, 2) STRIP_CASE(2, 256, 1) STRIP_CASE(2, 256, 2)
-    STRIP_CASE(3, 64, 1) STRIP_CASE(3, 64, 2) STRIP_CASE(3, 128, 1) STRIP_CASE(3, 128, 2) STRIP_CASE(3, 256, 1) STRIP_CASE(3, 256, 2)
-    STRIP_CASE(4, 64, 1) STRIP_CASE(4, 64, 2) STRIP_CASE(4, 128, 1) STRIP_CASE(4, 128, 2) STRIP_CASE(4, 256, 1) STRIP_CASE(4, 256, 2)
-    STRIP_CASE(5, 64, 1) STRIP_CASE(5, 64, 2) STRIP_CASE(5, 128, 1) STRIP_CASE(5, 128, 2) STRIP_CASE(5, 256, 1) STRIP_CASE(5, 256, 2)
+    STRIP_CASE(1, 128, 1) STRIP_CASE(1, 128, 2) STRIP_CASE(1, 256, 1) STRIP_CASE(1, 256, 2)
+    STRIP_CASE(2, 128, 1) STRIP_CASE(2, 128, 2) STRIP_CASE(2, 256, 1) STRIP_CASE(2, 256, 2)
+    STRIP_CASE(3, 128, 1) STRIP_CASE(3, 128, 2) STRIP_CASE(3, 256, 1) STRIP_CASE(3, 256, 2)
+    STRIP_CASE(4, 128, 1) STRIP_CASE(4, 128, 2) STRIP_CASE(4, 256, 1) STRIP_CASE(4, 256, 2)
+    STRIP_CASE(5, 128, 1) STRIP_CASE(5, 128, 2) STRIP_CASE(5, 256, 1) STRIP_CASE(5, 256, 2)
     return hipErrorInvalidValue;
 }
