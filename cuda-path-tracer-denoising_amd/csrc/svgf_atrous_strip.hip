@@ -351,12 +351,82 @@ __global__ __launch_bounds__(TX * ROWS + kLoaderThreads) void k_atrous_strip(Atr
                 acc.ww = v2f{w0, w0 * w0};
                 acc.rg = v2f{w0 * C.x, w0 * C.y};
                 acc.bv = v2f{w0 * C.z, (w0 * w0) * C.w};
+                // A tap row (5 taps) is evaluated in stages so that the five taps' dependency chains interleave and the
+                // transcendentals issue back to back (measured: clustered v_sqrt/v_exp overlap with packed VALU, spread
+                // ones do not — profiles/r01_ubench2_trans_overlap.log).  The geometry slots {A,B} of row j+1 are
+                // prefetched while row j is evaluated; the colour slot C of row j is fetched behind its geometry math.
+                v4f Ac[5], Bc[5], An[5], Bn[5];
+                {
+                    const char *rowp = colbase + (size_t)slot_of(bo - 2) * RW * PXB;
+#pragma unroll
+                    for (int i = 0; i < 5; i++) {
+                        Ac[i] = *reinterpret_cast<const v4f *>(rowp + i * S * PXB);
+                        Bc[i] = *reinterpret_cast<const v4f *>(rowp + i * S * PXB + 16);
+                    }
+                }
 #pragma unroll
                 for (int j = -2; j <= 2; j++) {
                     const char *rowp = colbase + (size_t)slot_of(bo + j) * RW * PXB;
+                    if (j < 2) {
+                        const char *rown = colbase + (size_t)slot_of(bo + j + 1) * RW * PXB;
 #pragma unroll
-                    for (int i = -2; i <= 2; i++)
-                        if (i != 0 || j != 0) tap<false>(rowp + (i + 2) * S * PXB, neg_log2_binom(i) + neg_log2_binom(j), c, acc);
+                        for (int i = 0; i < 5; i++) {
+                            An[i] = *reinterpret_cast<const v4f *>(rown + i * S * PXB);
+                            Bn[i] = *reinterpret_cast<const v4f *>(rown + i * S * PXB + 16);
+                        }
+                    }
+                    v2f s2[5];
+                    float dl[5];
+#pragma unroll
+                    for (int i = 0; i < 5; i++) {
+                        if (i == 2 && j == 0) continue;
+                        const v2f d0 = Ac[i].xy - c.nx_px, d1 = Ac[i].zw - c.ny_py, d2 = Bc[i].xy - c.nz_pz;
+                        v2f t = d0 * d0;
+                        t = __builtin_elementwise_fma(d1, d1, t);
+                        s2[i] = __builtin_elementwise_fma(d2, d2, t);
+                        dl[i] = Bc[i].z - c.lp;
+                    }
+                    v4f Cc[5];
+#pragma unroll
+                    for (int i = 0; i < 5; i++)
+                        if (!(i == 2 && j == 0)) Cc[i] = *reinterpret_cast<const v4f *>(rowp + i * S * PXB + 32);
+                    __builtin_amdgcn_sched_barrier(0x100);      // only LDS reads may move across
+                    float dn[5], dx[5];
+#pragma unroll
+                    for (int i = 0; i < 5; i++) {
+                        if (i == 2 && j == 0) continue;
+                        dn[i] = __builtin_amdgcn_sqrtf(s2[i].x);
+                        dx[i] = __builtin_amdgcn_sqrtf(s2[i].y);
+                    }
+                    __builtin_amdgcn_sched_barrier(0x100);
+                    float e[5];
+#pragma unroll
+                    for (int i = 0; i < 5; i++) {
+                        if (i == 2 && j == 0) continue;
+                        float t = fmaf(fabsf(dl[i]), c.kl, neg_log2_binom(i - 2) + neg_log2_binom(j));
+                        t = fmaf(dn[i], c.kn, t);
+                        e[i] = fmaf(dx[i], c.kx, t);
+                    }
+                    __builtin_amdgcn_sched_barrier(0x100);
+                    float w[5];
+#pragma unroll
+                    for (int i = 0; i < 5; i++)
+                        if (!(i == 2 && j == 0)) w[i] = __builtin_amdgcn_exp2f(-e[i]);
+                    __builtin_amdgcn_sched_barrier(0x100);
+#pragma unroll
+                    for (int i = 0; i < 5; i++) {
+                        if (i == 2 && j == 0) continue;
+                        v2f wv;
+                        wv.x = w[i];
+                        wv.y = w[i] * w[i];
+                        acc.ww += wv;
+                        acc.rg = __builtin_elementwise_fma(Cc[i].xy, v2f{w[i], w[i]}, acc.rg);
+                        acc.bv = __builtin_elementwise_fma(Cc[i].zw, wv, acc.bv);
+                    }
+                    if (j < 2) {
+#pragma unroll
+                        for (int i = 0; i < 5; i++) { Ac[i] = An[i]; Bc[i] = Bn[i]; }
+                    }
                 }
             } else {
                 acc.rg = v2f{0.0f, 0.0f}; acc.bv = v2f{0.0f, 0.0f}; acc.ww = v2f{0.0f, 0.0f};
