@@ -122,6 +122,12 @@ def main():
         raise SystemExit("bench: non-finite output")
 
     if rank == 0:
+        traffic = None
+        try:   # HBM bytes per launch from the committed PMC passes (profiles/pmc_traffic.json); not re-measured live
+            with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+                traffic = json.load(f)["mean_bytes_per_launch"]
+        except Exception:
+            traffic = None
         value = pixels / dt / 1e6
         a_ms = float(np.mean(atrous_ms))
         achieved = ATROUS_BYTES_PER_PIXEL * W * H / (a_ms * 1e-3) / 1e9
@@ -134,7 +140,8 @@ def main():
                                    "static camera, steady-state history; one independent sequence per GPU",
                        "width": W, "height": H, "atrous_levels": NLEVEL, "parallelism": f"replicas{world}"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, profiles/pmc_traffic.json (FETCH x2 per MI355X_MICROARCH.md)",
                          "kernel": "k_atrous_strip (one a-trous level)", "bytes_per_launch": ATROUS_BYTES_PER_PIXEL * W * H,
                          "mean_launch_us": round(a_ms * 1e3, 2), "launches_timed": len(atrous_ms)},
             "kernels_us": {"temporal": round(float(np.mean(temporal_ms)) * 1e3, 2), "atrous_level_mean": round(a_ms * 1e3, 2)},

@@ -14,7 +14,8 @@
 // Wave specialisation.  Measured on MI355X (profiles/r01_strip_phase_timeline.log): with every wave doing
 // load -> math -> store -> barrier in lockstep, the 25-tap math ran VALU-saturated but only ~45 % of the time; the
 // rest was vector-memory issue, LDS staging and barrier skew that nothing overlapped.  The workgroup is therefore
-// TX*ROWS compute threads + two loader groups (2 waves each) that alternate iterations: a loader fetches the next ROWS lattice rows (and the two
+// TX*ROWS compute threads + three loader groups (2 waves each) that take turns: a loader fetches the next ROWS lattice
+// rows (and the two
 // full-resolution neighbour rows the 3x3 variance pre-blur needs) while the compute waves evaluate taps, converts
 // them to the LDS layout and publishes them at the single barrier that ends the iteration.  Compute waves issue no
 // vector-memory loads at all.
@@ -41,8 +42,9 @@
 namespace {
 
 constexpr float kLog2e = 1.44269504088896340736f;
-constexpr int kLoaderGroup = 128;                 // threads per loader group (two waves)
-constexpr int kLoaderThreads = 2 * kLoaderGroup;  // two groups alternate iterations
+constexpr int kLoaderGroup = 128;                               // threads per loader group (two waves)
+constexpr int kLoaderGroups = 3;                                // groups take turns: issue / in flight / commit
+constexpr int kLoaderThreads = kLoaderGroups * kLoaderGroup;
 
 struct StripGeom {
     int n_strips;   // strips of TX columns
@@ -236,10 +238,11 @@ __global__ __launch_bounds__(TX * ROWS + kLoaderThreads) void k_atrous_strip(Atr
         }
     };
 
-    // Loader groups: two groups of kLoaderGroup threads; group q owns the rows that iterations j with (j & 1) == q
-    // newly need.  A group issues its loads at the start of iteration j-2, keeps them in flight across that
-    // iteration's barrier, converts and stores them during iteration j-1, and the barrier ending j-1 publishes them:
-    // every global load has a whole iteration (~2-3 us) to land, and each group only works every other iteration.
+    // Loader groups: kLoaderGroups groups of kLoaderGroup threads; group q owns the rows that iterations j with
+    // j % kLoaderGroups == q newly need.  A group issues its loads at the start of iteration j-kLoaderGroups, keeps
+    // them in flight across kLoaderGroups-1 barriers, converts and stores them during iteration j-1, and the barrier
+    // ending j-1 publishes them: every global load has kLoaderGroups-1 whole iterations (~2 x 3.5 us) to land — at 4K
+    // the planes no longer sit in the Infinity Cache and one iteration was not enough (profiles/r01_strip_timeline_4k.log).
     constexpr int ML = (ROWS * RW + kLoaderGroup - 1) / kLoaderGroup;
     constexpr int MBL = (ROWS * 2 * BW + kLoaderGroup - 1) / kLoaderGroup;
     const bool is_loader = (tid >= NC);
@@ -275,7 +278,7 @@ __global__ __launch_bounds__(TX * ROWS + kLoaderThreads) void k_atrous_strip(Atr
         rows_store(px, b0 - 2, 4 + ROWS, tid, NT);
         if (a.blur_variance) blur_store(bv, 0, tid, NT);
     }
-    if (lgroup == 1) loader_issue(1);
+    if (is_loader && lgroup >= 1) loader_issue(lgroup);     // iterations 1 .. kLoaderGroups-1: issue before the first barrier
     __syncthreads();
 
     int dbg_it = 0;
@@ -290,8 +293,8 @@ __global__ __launch_bounds__(TX * ROWS + kLoaderThreads) void k_atrous_strip(Atr
         int it = 0;
         for (int bc = b0; bc < b1; bc += ROWS, it++, dbg_it++) {
             stamp(0);
-            if (((it + 1) & 1) == lgroup) loader_commit(it + 1);   // loads were issued during iteration it-1
-            else loader_issue(it + 2);
+            if ((it + 1) % kLoaderGroups == lgroup) loader_commit(it + 1);          // issued kLoaderGroups-1 iterations ago
+            else if (it % kLoaderGroups == lgroup) loader_issue(it + kLoaderGroups);
             stamp(5);
             __syncthreads();
             stamp(6);
@@ -497,7 +500,7 @@ hipError_t launch_cfg(const AtrousArgs &a, hipStream_t s)
         const long blocks = (long)gm.n_strips * S * segs_l;
         const long rounds = (blocks + capacity - 1) / capacity;
         const long cost = rounds * (L + 8);
-        if (best_cost < 0 || cost < best_cost) { best_cost = cost; best_L = L; }
+        if (best_cost < 0 || cost <= best_cost) { best_cost = cost; best_L = L; }   // ties: fewer, longer workgroups
     }
     if (const char *e = getenv("SVGF_STRIP_SEGROWS")) { int v = atoi(e); if (v > 0) best_L = ((v + ROWS - 1) / ROWS) * ROWS; }
     gm.seg_rows = best_L;
@@ -523,14 +526,14 @@ hipError_t launch_cfg(const AtrousArgs &a, hipStream_t s)
         (void)hipMemcpy(h, dbg_buf, sizeof(h), hipMemcpyDeviceToHost);
         if (prints++ < 10) {
             const int nw = (TX * ROWS + kLoaderThreads) / 64;
-            fprintf(stderr, "[strip dbg] S=%d TX=%d ROWS=%d blocks=%d segs=%d seg_rows=%d lds=%zu waves=%d (last 4 = loaders)\n", S, TX,
+            fprintf(stderr, "[strip dbg] S=%d TX=%d ROWS=%d blocks=%d segs=%d seg_rows=%d lds=%zu waves=%d (last 6 = loaders)\n", S, TX,
                     ROWS, nblocks, gm.n_segs, gm.seg_rows, lds, nw);
-            const int show[4] = { 0, nw - 5, nw - 4, nw - 2 };
+            const int show[4] = { 0, nw - 2 * kLoaderGroups - 1, nw - 2 * kLoaderGroups, nw - 2 };
             for (int si = 0; si < 4; si++) {
                 const int w = show[si];
                 for (int it = 0; it < 16 && h[(w * 16 + it) * 8]; it++) {
                     unsigned long long *t = &h[(w * 16 + it) * 8];
-                    if (w >= nw - 4)
+                    if (w >= nw - 2 * kLoaderGroups)
                         fprintf(stderr, "  loader  it %2d: t0=%6llu stage %6llu barrier %5llu\n", it, t[0] - h[0], t[5] - t[0], t[6] - t[5]);
                     else
                         fprintf(stderr, "  wave %2d it %2d: t0=%6llu centre %5llu taps %6llu out %5llu barrier %5llu\n", w, it, t[0] - h[0],
