@@ -96,6 +96,8 @@ def main():
     out = torch.empty((H, W, 3), dtype=torch.float32, device=dev)
     den = pkg.Denoiser(W, H, device=local_rank)
     stream = torch.cuda.current_stream(dev)
+    PROFILE_STRIDE = 8      # HIP-event pairs around every kernel of every 8th timed step (they widen the launch gaps)
+    den.profile_stride(PROFILE_STRIDE)
     den.profile_enable(a.steps)
 
     def step(i):

@@ -27,7 +27,7 @@ MAX_LEVELS = 10
 # every symbol include/svgf.h declares
 EXPORTS = ["svgf_version", "svgf_params_default", "svgf_create", "svgf_destroy", "svgf_reset", "svgf_denoise",
            "svgf_denoise_host", "svgf_sync", "svgf_last_error", "svgf_width", "svgf_height", "svgf_read_state",
-           "svgf_set_capture", "svgf_profile_enable", "svgf_profile_frames", "svgf_profile_read"]
+           "svgf_set_capture", "svgf_profile_enable", "svgf_profile_stride", "svgf_profile_frames", "svgf_profile_read"]
 
 
 class SvgfCamera(C.Structure):
@@ -99,6 +99,7 @@ def load_library(path: str | None = None):
     lib.svgf_read_state.argtypes = [vp, ip, vp, C.c_ulonglong]
     lib.svgf_set_capture.argtypes = [vp, ip]
     lib.svgf_profile_enable.argtypes = [vp, ip]
+    lib.svgf_profile_stride.argtypes = [vp, ip]
     lib.svgf_profile_frames.argtypes = [vp]
     lib.svgf_profile_frames.restype = C.c_longlong
     lib.svgf_profile_read.argtypes = [vp, ip, ip, C.POINTER(ip), C.POINTER(C.c_float), C.POINTER(ip)]
@@ -196,6 +197,9 @@ class Denoiser:
     # --- profiling ---
     def profile_enable(self, nframes: int):
         self._check(self.lib.svgf_profile_enable(self.h, int(nframes)), "svgf_profile_enable")
+
+    def profile_stride(self, k: int):
+        self._check(self.lib.svgf_profile_stride(self.h, int(k)), "svgf_profile_stride")
 
     def profile_frames(self) -> int:
         return int(self.lib.svgf_profile_frames(self.h))

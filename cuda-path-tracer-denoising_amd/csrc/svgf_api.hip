@@ -38,6 +38,8 @@ struct svgf_ctx {
     float *st_in, *st_out; void *st_g;
     // profiling
     int prof_frames;       // 0 = off
+    int prof_stride;       // bracket every prof_stride-th frame
+    long long frame_no;    // frames denoised since profile_enable
     long long prof_count;  // frames recorded since enable
     hipEvent_t *ev;        // prof_frames * SVGF_MAX_KERNELS_PER_FRAME * 2
     int *ev_kind;          // prof_frames * SVGF_MAX_KERNELS_PER_FRAME
@@ -242,7 +244,8 @@ extern "C" int svgf_profile_enable(svgf_ctx *c, int nframes)
         free(c->ev); free(c->ev_kind); free(c->ev_n);
         c->ev = nullptr; c->ev_kind = nullptr; c->ev_n = nullptr;
     }
-    c->prof_frames = 0; c->prof_count = 0;
+    c->prof_frames = 0; c->prof_count = 0; c->frame_no = 0;
+    if (c->prof_stride < 1) c->prof_stride = 1;
     if (nframes == 0) return SVGF_OK;
     const long long ne = (long long)nframes * SVGF_MAX_KERNELS_PER_FRAME * 2;
     c->ev = (hipEvent_t *)calloc(ne, sizeof(hipEvent_t));
@@ -251,6 +254,13 @@ extern "C" int svgf_profile_enable(svgf_ctx *c, int nframes)
     if (!c->ev || !c->ev_kind || !c->ev_n) return SVGF_ERR_OOM;
     for (long long k = 0; k < ne; k++) HIPC(c, hipEventCreate(&c->ev[k]));
     c->prof_frames = nframes;
+    return SVGF_OK;
+}
+
+extern "C" int svgf_profile_stride(svgf_ctx *c, int k)
+{
+    if (!c || k < 1) return SVGF_ERR_INVALID_ARG;
+    c->prof_stride = k;
     return SVGF_OK;
 }
 
@@ -275,16 +285,16 @@ extern "C" int svgf_profile_read(svgf_ctx *c, int slot, int max_entries, int *ki
 
 namespace {
 struct KernelTimer {   // brackets one launch with an event pair when profiling is on
-    svgf_ctx *c; hipStream_t s; int slot; int k;
+    svgf_ctx *c; hipStream_t s; int slot; int k; bool on;
     bool begin(int kind) {
-        if (!c->prof_frames) return true;
+        if (!on) return true;
         k = c->ev_n[slot];
         if (k >= SVGF_MAX_KERNELS_PER_FRAME) return true;
         c->ev_kind[slot * SVGF_MAX_KERNELS_PER_FRAME + k] = kind;
         return hipEventRecord(c->ev[((long long)slot * SVGF_MAX_KERNELS_PER_FRAME + k) * 2], s) == hipSuccess;
     }
     bool end() {
-        if (!c->prof_frames || k >= SVGF_MAX_KERNELS_PER_FRAME) return true;
+        if (!on || k >= SVGF_MAX_KERNELS_PER_FRAME) return true;
         c->ev_n[slot] = k + 1;
         return hipEventRecord(c->ev[((long long)slot * SVGF_MAX_KERNELS_PER_FRAME + k) * 2 + 1], s) == hipSuccess;
     }
@@ -323,8 +333,9 @@ extern "C" int svgf_denoise(svgf_ctx *c, void *out_rgb_dev, const void *in_rgb_d
     const float *g = (const float *)gbuffer_dev;
     const int n = (int)c->n;
 
-    KernelTimer timer{ c, s, 0, 0 };
-    if (c->prof_frames) {
+    KernelTimer timer{ c, s, 0, 0, false };
+    if (c->prof_frames && (c->frame_no % (c->prof_stride > 0 ? c->prof_stride : 1)) == 0) {
+        timer.on = true;
         timer.slot = (int)(c->prof_count % c->prof_frames);
         c->ev_n[timer.slot] = 0;
     }
@@ -392,7 +403,8 @@ extern "C" int svgf_denoise(svgf_ctx *c, void *out_rgb_dev, const void *in_rgb_d
     if (p->temporal_enable) c->cur = 1 - c->cur;
     c->gcur = gnew;
     view_matrix_from_camera(cam, c->view_prev);
-    if (c->prof_frames) c->prof_count++;
+    if (timer.on) c->prof_count++;
+    c->frame_no++;
     return SVGF_OK;
 }
 

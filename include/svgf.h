@@ -146,7 +146,10 @@ int svgf_set_capture(svgf_ctx *ctx, int on);
 #define SVGF_KERNEL_ATROUS     3
 #define SVGF_KERNEL_DEBUGVIEW  4
 #define SVGF_KERNEL_COPYOUT    5
+/* svgf_profile_stride(ctx, k): bracket only every k-th frame (k >= 1, default 1); the event records lengthen the gaps
+ * between kernels by a few microseconds, so a throughput run samples a subset of its frames. */
 int svgf_profile_enable(svgf_ctx *ctx, int nframes);
+int svgf_profile_stride(svgf_ctx *ctx, int every_kth_frame);
 long long svgf_profile_frames(const svgf_ctx *ctx);
 int svgf_profile_read(svgf_ctx *ctx, int slot, int max_entries, int *kinds, float *ms, int *n_out);
 
