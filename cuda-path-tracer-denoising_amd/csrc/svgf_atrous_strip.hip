@@ -42,9 +42,9 @@
 namespace {
 
 constexpr float kLog2e = 1.44269504088896340736f;
-constexpr int kLoaderGroup = 128;                               // threads per loader group (two waves)
 constexpr int kLoaderGroups = 3;                                // groups take turns: issue / in flight / commit
-constexpr int kLoaderThreads = kLoaderGroups * kLoaderGroup;
+__host__ __device__ constexpr int loader_group(int tx) { return tx / 2; }            // threads per loader group
+__host__ __device__ constexpr int loader_threads(int tx) { return kLoaderGroups * loader_group(tx); }
 
 struct StripGeom {
     int n_strips;   // strips of TX columns
@@ -59,7 +59,7 @@ struct StripGeom {
 struct Px {   // one staged pixel in registers
     float4 cv;
     float nx, ny, nz, px, py, pz;
-    bool valid;
+    int lds_off;   // byte offset of its slot in the LDS ring; bit 31 set = out-of-image pixel
 };
 
 __device__ __forceinline__ float lum_f64(float r, float g, float b)
@@ -125,13 +125,15 @@ __device__ __forceinline__ constexpr float neg_log2_binom(int i)
 }
 
 template <int LOG2S, int TX, int ROWS>
-__global__ __launch_bounds__(TX * ROWS + kLoaderThreads) void k_atrous_strip(AtrousArgs a, StripGeom gm)
+__global__ __launch_bounds__(TX * ROWS + loader_threads(TX)) void k_atrous_strip(AtrousArgs a, StripGeom gm)
 {
     constexpr int S = 1 << LOG2S;
     constexpr int RW = TX + 4 * S;          // staged pixels per lattice row
     constexpr int R = 4 + 2 * ROWS;         // ring slots: 4 + ROWS live, ROWS incoming
     constexpr int PXB = 48;                 // bytes per staged pixel
     constexpr int NC = TX * ROWS;           // compute threads
+    constexpr int kLoaderGroup = loader_group(TX);
+    constexpr int kLoaderThreads = loader_threads(TX);
     constexpr int NT = NC + kLoaderThreads; // + the loader waves
     constexpr int BW = TX + 2;              // blur row: columns x0-1 .. x0+TX
     constexpr int RING_BYTES = R * RW * PXB;
@@ -165,52 +167,43 @@ __global__ __launch_bounds__(TX * ROWS + kLoaderThreads) void k_atrous_strip(Atr
     // ---- staging, split in two halves so that a batch of loads can stay in flight across a barrier ----
     // rows_load : global -> registers for lattice rows br_first .. br_first+nrows-1, pixels wi, wi+nw, ...
     // rows_store: registers -> LDS ring (layout conversion, luminance, non-finite detection)
+    // Both are branch-free: coordinates are clamped into the image so every lane always loads valid memory, and an
+    // out-of-image pixel is then encoded as {luminance = +inf, colour/variance = 0} (weight exp2(-inf) = 0; the zeroed
+    // colour keeps 0 * x finite).  Its normal/position slots keep the clamped pixel's finite values.
     auto rows_load = [&](auto &px, int br_first, int nrows, int wi, int nw) {
         constexpr int M = sizeof(px) / sizeof(px[0]);
+        const int total = nrows * RW;
 #pragma unroll
         for (int m = 0; m < M; m++) {
-            const int idx = wi + m * nw;
-            px[m].valid = false;
-            if (idx < nrows * RW) {
-                const int rr = idx / RW, xi = idx - rr * RW;
-                const int br = br_first + rr;
-                const int y = phase + (br << LOG2S);
-                const int xs = x0 - 2 * S + xi;
-                px[m].valid = (br >= 0) && (y < H) && (xs >= 0) && (xs < W);
-                if (px[m].valid) {
-                    const unsigned q = (unsigned)y * (unsigned)W + (unsigned)xs;   // < 2^28 (checked on the host)
-                    px[m].cv = a.src[q];
-                    const float *n = a.nrm + 3u * q;
-                    const float *p = a.pos + 3u * q;
-                    px[m].nx = n[0]; px[m].ny = n[1]; px[m].nz = n[2];
-                    px[m].px = p[0]; px[m].py = p[1]; px[m].pz = p[2];
-                }
-            }
+            const int idx = min(wi + m * nw, total - 1);       // surplus lanes repeat the last pixel (same value, same slot)
+            const int rr = idx / RW, xi = idx - rr * RW;
+            const int br = br_first + rr;
+            const int y = phase + (br << LOG2S);
+            const int xs = x0 - 2 * S + xi;
+            const bool ok = (br >= 0) && (y < H) && (xs >= 0) && (xs < W);
+            px[m].lds_off = ((slot_of(br) * RW + xi) * PXB) | (ok ? 0 : (int)0x80000000);
+            const unsigned q = (unsigned)min(max(y, 0), H - 1) * (unsigned)W + (unsigned)min(max(xs, 0), W - 1);   // < 2^28
+            // 32-bit byte offsets from the (wave-uniform) plane bases: global_load with SGPR base + VGPR offset
+            px[m].cv = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(a.src) + q * 16u);
+            const float *n = reinterpret_cast<const float *>(reinterpret_cast<const char *>(a.nrm) + q * 12u);
+            const float *p = reinterpret_cast<const float *>(reinterpret_cast<const char *>(a.pos) + q * 12u);
+            px[m].nx = n[0]; px[m].ny = n[1]; px[m].nz = n[2];
+            px[m].px = p[0]; px[m].py = p[1]; px[m].pz = p[2];
         }
     };
-    auto rows_store = [&](const auto &px, int br_first, int nrows, int wi, int nw) {
+    auto rows_store = [&](const auto &px) {
         constexpr int M = sizeof(px) / sizeof(px[0]);
+        const float inf = __builtin_huge_valf();
 #pragma unroll
         for (int m = 0; m < M; m++) {
-            const int idx = wi + m * nw;
-            if (idx < nrows * RW) {
-                const int rr = idx / RW, xi = idx - rr * RW;
-                float4 A, B, C;
-                if (px[m].valid) {
-                    A = make_float4(px[m].nx, px[m].px, px[m].ny, px[m].py);
-                    B = make_float4(px[m].nz, px[m].pz, lum_f64(px[m].cv.x, px[m].cv.y, px[m].cv.z), 0.0f);
-                    C = px[m].cv;
-                    if (!finite3(px[m].nx, px[m].ny, px[m].nz) || !finite3(px[m].px, px[m].py, px[m].pz)) *nan_seen = 1;
-                } else {
-                    A = make_float4(0.f, 0.f, 0.f, 0.f);
-                    B = make_float4(0.f, 0.f, __builtin_huge_valf(), 0.f);   // luminance = +inf => weight 0
-                    C = make_float4(0.f, 0.f, 0.f, 0.f);
-                }
-                char *d = smem + ((size_t)slot_of(br_first + rr) * RW + xi) * PXB;
-                *reinterpret_cast<float4 *>(d) = A;
-                *reinterpret_cast<float4 *>(d + 16) = B;
-                *reinterpret_cast<float4 *>(d + 32) = C;
-            }
+            const bool ok = px[m].lds_off >= 0;
+            const float lum = lum_f64(px[m].cv.x, px[m].cv.y, px[m].cv.z);
+            const float mag = fabsf(px[m].nx) + fabsf(px[m].ny) + fabsf(px[m].nz) + fabsf(px[m].px) + fabsf(px[m].py) + fabsf(px[m].pz);
+            if (!(mag < inf)) *nan_seen = 1;                    // NaN or inf in a normal / position (rare)
+            char *d = smem + (px[m].lds_off & 0x7fffffff);
+            *reinterpret_cast<float4 *>(d) = make_float4(px[m].nx, px[m].px, px[m].ny, px[m].py);
+            *reinterpret_cast<float4 *>(d + 16) = make_float4(px[m].nz, px[m].pz, ok ? lum : inf, 0.0f);
+            *reinterpret_cast<float4 *>(d + 32) = ok ? px[m].cv : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
     // variance of the full-resolution rows y-1 and y+1 of output rows bo_first .. +ROWS-1 (3x3 pre-blur, :102-118)
@@ -261,7 +254,7 @@ __global__ __launch_bounds__(TX * ROWS + kLoaderThreads) void k_atrous_strip(Atr
     auto loader_commit = [&](int j) {
         const int bcj = b0 + j * ROWS;
         if (bcj < b1) {
-            rows_store(lpx, bcj + 2, ROWS, llane, kLoaderGroup);
+            rows_store(lpx);
             if (a.blur_variance) blur_store(lbv, j & 1, llane, kLoaderGroup);
         }
     };
@@ -275,7 +268,7 @@ __global__ __launch_bounds__(TX * ROWS + kLoaderThreads) void k_atrous_strip(Atr
         constexpr int MB = (ROWS * 2 * BW + NT - 1) / NT;
         float bv[MB];
         blur_load(bv, b0, tid, NT);
-        rows_store(px, b0 - 2, 4 + ROWS, tid, NT);
+        rows_store(px);
         if (a.blur_variance) blur_store(bv, 0, tid, NT);
     }
     if (is_loader && lgroup >= 1) loader_issue(lgroup);     // iterations 1 .. kLoaderGroups-1: issue before the first barrier
@@ -490,6 +483,7 @@ hipError_t launch_cfg(const AtrousArgs &a, hipStream_t s)
         if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) n_cu = 256;
     }
     int bpc = (int)((160 * 1024) / lds);
+    constexpr int kLoaderThreads = loader_threads(TX);
     if (bpc > 2048 / (TX * ROWS + kLoaderThreads)) bpc = 2048 / (TX * ROWS + kLoaderThreads);
     if (bpc < 1) bpc = 1;
     const int capacity = n_cu * bpc;
@@ -528,12 +522,13 @@ hipError_t launch_cfg(const AtrousArgs &a, hipStream_t s)
             const int nw = (TX * ROWS + kLoaderThreads) / 64;
             fprintf(stderr, "[strip dbg] S=%d TX=%d ROWS=%d blocks=%d segs=%d seg_rows=%d lds=%zu waves=%d (last 6 = loaders)\n", S, TX,
                     ROWS, nblocks, gm.n_segs, gm.seg_rows, lds, nw);
-            const int show[4] = { 0, nw - 2 * kLoaderGroups - 1, nw - 2 * kLoaderGroups, nw - 2 };
+            const int nlw = kLoaderThreads / 64;
+            const int show[4] = { 0, nw - nlw - 1, nw - nlw, nw - 1 };
             for (int si = 0; si < 4; si++) {
                 const int w = show[si];
                 for (int it = 0; it < 16 && h[(w * 16 + it) * 8]; it++) {
                     unsigned long long *t = &h[(w * 16 + it) * 8];
-                    if (w >= nw - 2 * kLoaderGroups)
+                    if (w >= nw - nlw)
                         fprintf(stderr, "  loader  it %2d: t0=%6llu stage %6llu barrier %5llu\n", it, t[0] - h[0], t[5] - t[0], t[6] - t[5]);
                     else
                         fprintf(stderr, "  wave %2d it %2d: t0=%6llu centre %5llu taps %6llu out %5llu barrier %5llu\n", w, it, t[0] - h[0],
