@@ -47,7 +47,8 @@ class SvgfParams(C.Structure):
                 ("moment_alpha", C.c_float), ("blur_variance", C.c_int), ("sigma_l", C.c_float),
                 ("sigma_x", C.c_float), ("sigma_n", C.c_float), ("atrous_nlevel", C.c_int),
                 ("history_level", C.c_int), ("sepcolor", C.c_int), ("addcolor", C.c_int),
-                ("right_view_option", C.c_int), ("kernel_variant", C.c_int), ("reserved", C.c_int * 3)]
+                ("right_view_option", C.c_int), ("kernel_variant", C.c_int), ("inputs_ready", C.c_int),
+                ("reserved", C.c_int * 2)]
 
     def set(self, **kw):
         for k, v in kw.items():
@@ -79,6 +80,14 @@ def load_library(path: str | None = None):
     if _lib is not None and path is None:
         return _lib
     path = path or LIB_PATH
+    # PyTorch-ROCm wheels bundle their own libamdhip64.so.  If this library were loaded first it would bind the
+    # system copy, and a process in which two HIP runtimes initialise can end up with one of them seeing no device.
+    # Importing torch first (when it is installed) makes both share the copy torch already mapped.  torch is not
+    # otherwise needed by the library.
+    try:
+        import torch  # noqa: F401
+    except Exception:
+        pass
     if not os.path.exists(path):
         raise SvgfError(f"{path} not found: build it first (python -c 'import __graft_entry__ as g; g.build()'). "
                         "There is no CPU fallback.")

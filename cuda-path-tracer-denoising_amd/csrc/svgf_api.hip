@@ -20,16 +20,22 @@
 struct svgf_ctx {
     int device, W, H;
     size_t n;
-    float4 *cv[3];
+    float4 *cv[4];
     float *nrm[2];
     int *gid[2];
-    float *pos;
+    float *pos[2];
     float2 *mom[2];
     int *hlen[2];
     int hist;      // cv index holding the colour history
     int acc;       // cv index the last temporal pass wrote
     int cur;       // mom/hlen index holding the history the next frame reads
-    int gcur;      // nrm/gid index holding the previous frame's planes
+    int gcur;      // nrm/gid/pos index holding the previous frame's planes
+    // cross-frame overlap (SvgfParams::inputs_ready): the temporal pass of frame f+1 runs on `side` concurrently with the
+    // a-trous levels of frame f that come after the level feeding the colour history
+    hipStream_t side;
+    hipEvent_t ev_hist, ev_temporal;
+    int ev_hist_valid;
+    unsigned inflight_mask;   // cv planes the previous frame's levels after its history level still write
     float view_prev[16];   // column-major; identity until the first frame (reference src/denoise.cu:15)
     // state capture for tests
     int capture;
@@ -112,14 +118,17 @@ extern "C" int svgf_params_default(SvgfParams *p)
 
 static void free_all(svgf_ctx *c)
 {
-    for (int k = 0; k < 3; k++) if (c->cv[k]) (void)hipFree(c->cv[k]);
+    for (int k = 0; k < 4; k++) if (c->cv[k]) (void)hipFree(c->cv[k]);
     for (int k = 0; k < 2; k++) {
         if (c->nrm[k]) (void)hipFree(c->nrm[k]);
         if (c->gid[k]) (void)hipFree(c->gid[k]);
         if (c->mom[k]) (void)hipFree(c->mom[k]);
         if (c->hlen[k]) (void)hipFree(c->hlen[k]);
     }
-    if (c->pos) (void)hipFree(c->pos);
+    for (int k = 0; k < 2; k++) if (c->pos[k]) (void)hipFree(c->pos[k]);
+    if (c->side) (void)hipStreamDestroy(c->side);
+    if (c->ev_hist) (void)hipEventDestroy(c->ev_hist);
+    if (c->ev_temporal) (void)hipEventDestroy(c->ev_temporal);
     if (c->cv_capture) (void)hipFree(c->cv_capture);
     if (c->st_in) (void)hipFree(c->st_in);
     if (c->st_out) (void)hipFree(c->st_out);
@@ -132,15 +141,16 @@ static void free_all(svgf_ctx *c)
 
 static int zero_state(svgf_ctx *c)
 {
-    for (int k = 0; k < 3; k++) HIPC(c, hipMemset(c->cv[k], 0, c->n * sizeof(float4)));
+    for (int k = 0; k < 4; k++) HIPC(c, hipMemset(c->cv[k], 0, c->n * sizeof(float4)));
     for (int k = 0; k < 2; k++) {
         HIPC(c, hipMemset(c->nrm[k], 0, c->n * 3 * sizeof(float)));
         HIPC(c, hipMemset(c->gid[k], 0, c->n * sizeof(int)));
         HIPC(c, hipMemset(c->mom[k], 0, c->n * sizeof(float2)));
         HIPC(c, hipMemset(c->hlen[k], 0, c->n * sizeof(int)));
+        HIPC(c, hipMemset(c->pos[k], 0, c->n * 3 * sizeof(float)));
     }
-    HIPC(c, hipMemset(c->pos, 0, c->n * 3 * sizeof(float)));
     c->hist = 0; c->acc = 0; c->cur = 0; c->gcur = 0;
+    c->ev_hist_valid = 0; c->inflight_mask = 0;
     return SVGF_OK;
 }
 
@@ -169,14 +179,21 @@ extern "C" int svgf_create(int device, int width, int height, svgf_ctx **out)
     c->device = device; c->W = width; c->H = height; c->n = (size_t)width * height;
     for (int k = 0; k < 16; k++) c->view_prev[k] = (k % 5 == 0) ? 1.0f : 0.0f;
     bool ok = true;
-    for (int k = 0; k < 3 && ok; k++) ok = hipMalloc((void **)&c->cv[k], c->n * sizeof(float4)) == hipSuccess;
+    for (int k = 0; k < 4 && ok; k++) ok = hipMalloc((void **)&c->cv[k], c->n * sizeof(float4)) == hipSuccess;
     for (int k = 0; k < 2 && ok; k++) {
         ok = ok && hipMalloc((void **)&c->nrm[k], c->n * 3 * sizeof(float)) == hipSuccess;
         ok = ok && hipMalloc((void **)&c->gid[k], c->n * sizeof(int)) == hipSuccess;
         ok = ok && hipMalloc((void **)&c->mom[k], c->n * sizeof(float2)) == hipSuccess;
         ok = ok && hipMalloc((void **)&c->hlen[k], c->n * sizeof(int)) == hipSuccess;
+        ok = ok && hipMalloc((void **)&c->pos[k], c->n * 3 * sizeof(float)) == hipSuccess;
     }
-    ok = ok && hipMalloc((void **)&c->pos, c->n * 3 * sizeof(float)) == hipSuccess;
+    {
+        int lo = 0, hi = 0;   // the side stream carries the short, latency-sensitive temporal pass: highest priority
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+        ok = ok && hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, hi) == hipSuccess;
+    }
+    ok = ok && hipEventCreateWithFlags(&c->ev_hist, hipEventDisableTiming) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&c->ev_temporal, hipEventDisableTiming) == hipSuccess;
     if (!ok) {
         snprintf(g_create_err, sizeof(g_create_err), "svgf_create: hipMalloc failed for %dx%d", width, height);
         free_all(c); delete c;
@@ -340,28 +357,65 @@ extern "C" int svgf_denoise(svgf_ctx *c, void *out_rgb_dev, const void *in_rgb_d
         c->ev_n[timer.slot] = 0;
     }
 
-    // 1) temporal accumulation, or constant variance (reference :360-371).  Writes the cv plane `acc` (never the
-    //    one holding the colour history) and the current-frame G-buffer planes.
-    const int acc = (c->hist + 1) % 3;
+    // 1) temporal accumulation, or constant variance (reference :360-371).  Writes a cv plane `acc` that neither holds
+    //    the colour history nor is still written by the previous frame's trailing a-trous levels, and the current-frame
+    //    G-buffer planes.
+    //    Cross-frame overlap: when the caller promises that the inputs are complete at call time (inputs_ready), this
+    //    pass runs on the context's side stream as soon as the level feeding the colour history of the PREVIOUS frame
+    //    is done, i.e. concurrently with that frame's remaining levels.  The temporal pass is HBM-bound and the a-trous
+    //    levels are VALU-bound, so the two kernels share the CUs well.
+    const bool overlap = (p->inputs_ready != 0);
+    int acc = -1;
+    for (int k = 0; k < 4; k++) if (k != c->hist && !((c->inflight_mask >> k) & 1u)) { acc = k; break; }
+    if (acc < 0) { snprintf(c->err, sizeof(c->err), "svgf_denoise: internal error, no free colour plane"); return SVGF_ERR_HIP; }
     const int gnew = 1 - c->gcur;
-    if (p->temporal_enable) {
-        TemporalArgs t;
-        t.in_rgb = in; t.gbuf = g; t.cv_hist = c->cv[c->hist]; t.cv_acc = c->cv[acc];
-        t.mom_hist = c->mom[c->cur]; t.mom_acc = c->mom[1 - c->cur];
-        t.hlen = c->hlen[c->cur]; t.hlen_upd = c->hlen[1 - c->cur];
-        t.nrm_prev = c->nrm[c->gcur]; t.gid_prev = c->gid[c->gcur];
-        t.nrm_cur = c->nrm[gnew]; t.gid_cur = c->gid[gnew]; t.pos_cur = c->pos;
-        memcpy(t.M, c->view_prev, sizeof(t.M));
-        t.W = c->W; t.H = c->H; t.color_alpha_min = p->color_alpha; t.moment_alpha_min = p->moment_alpha;
-        LAUNCH(SVGF_KERNEL_TEMPORAL, launch_temporal(t, s));
-    } else {
-        LAUNCH(SVGF_KERNEL_PREPARE, launch_prepare(in, g, c->cv[acc], c->nrm[gnew], c->gid[gnew], c->pos, c->W, c->H, s));
+    hipStream_t ts = overlap ? c->side : s;
+    if (overlap && c->ev_hist_valid) HIPC(c, hipStreamWaitEvent(c->side, c->ev_hist, 0));
+    {
+        KernelTimer timer_t = timer; timer_t.s = ts;
+        KernelTimer &timer_ref = timer_t;
+#define LAUNCH_T(kind, expr)                                                                         \
+    do {                                                                                             \
+        if (!timer_ref.begin(kind)) { snprintf(c->err, sizeof(c->err), "hipEventRecord failed"); return SVGF_ERR_HIP; } \
+        HIPC(c, (expr));                                                                             \
+        if (!timer_ref.end()) { snprintf(c->err, sizeof(c->err), "hipEventRecord failed"); return SVGF_ERR_HIP; }       \
+    } while (0)
+        if (p->temporal_enable) {
+            TemporalArgs t;
+            t.in_rgb = in; t.gbuf = g; t.cv_hist = c->cv[c->hist]; t.cv_acc = c->cv[acc];
+            t.mom_hist = c->mom[c->cur]; t.mom_acc = c->mom[1 - c->cur];
+            t.hlen = c->hlen[c->cur]; t.hlen_upd = c->hlen[1 - c->cur];
+            t.nrm_prev = c->nrm[c->gcur]; t.gid_prev = c->gid[c->gcur];
+            t.nrm_cur = c->nrm[gnew]; t.gid_cur = c->gid[gnew]; t.pos_cur = c->pos[gnew];
+            memcpy(t.M, c->view_prev, sizeof(t.M));
+            t.W = c->W; t.H = c->H; t.color_alpha_min = p->color_alpha; t.moment_alpha_min = p->moment_alpha;
+            LAUNCH_T(SVGF_KERNEL_TEMPORAL, launch_temporal(t, ts, overlap && c->ev_hist_valid));
+        } else {
+            LAUNCH_T(SVGF_KERNEL_PREPARE, launch_prepare(in, g, c->cv[acc], c->nrm[gnew], c->gid[gnew], c->pos[gnew], c->W, c->H, ts));
+        }
+#undef LAUNCH_T
     }
     c->acc = acc;
     c->hist = acc;                                   // color_history <- color_acc / input (:366,370)
-    if (c->capture) HIPC(c, hipMemcpyAsync(c->cv_capture, c->cv[acc], c->n * sizeof(float4), hipMemcpyDeviceToDevice, s));
+    if (c->capture) HIPC(c, hipMemcpyAsync(c->cv_capture, c->cv[acc], c->n * sizeof(float4), hipMemcpyDeviceToDevice, ts));
+    if (overlap) {
+        HIPC(c, hipEventRecord(c->ev_temporal, c->side));
+        HIPC(c, hipStreamWaitEvent(s, c->ev_temporal, 0));
+    }
+    c->inflight_mask = 0;
+    bool hist_final = false;         // has the kernel that produces next frame's colour history been enqueued?
+    auto mark_hist_final = [&]() -> bool {
+        hist_final = true;
+        if (hipEventRecord(c->ev_hist, s) != hipSuccess) return false;
+        c->ev_hist_valid = 1;
+        return true;
+    };
 
     // 2) debug views, pass-through or the a-trous cascade (:373-394)
+    const bool cascade = !(p->right_view_option == 1 || p->right_view_option == 2 || p->atrous_nlevel == 0 || !p->spatial_enable);
+    if (!cascade || p->history_level < 1 || p->history_level > p->atrous_nlevel) {
+        if (!mark_hist_final()) { snprintf(c->err, sizeof(c->err), "hipEventRecord failed"); return SVGF_ERR_HIP; }
+    }
     if (p->right_view_option == 1) {
         LAUNCH(SVGF_KERNEL_DEBUGVIEW, launch_debug_hlen(c->hlen[c->cur], out, n, 100.0f, s));   // pre-update lengths (:374)
     } else if (p->right_view_option == 2) {
@@ -375,11 +429,11 @@ extern "C" int svgf_denoise(svgf_ctx *c, void *out_rgb_dev, const void *in_rgb_d
             const bool keep = (level == p->history_level);      // this level's output becomes the colour history (:391)
             int dst = -1;
             if (!last || keep) {
-                for (int k = 0; k < 3; k++) if (k != src && k != c->hist) { dst = k; break; }
+                for (int k = 0; k < 4; k++) if (k != src && k != c->hist) { dst = k; break; }
             }
             AtrousArgs a;
             a.src = c->cv[src]; a.dst = dst >= 0 ? c->cv[dst] : nullptr; a.out_rgb = last ? out : nullptr;
-            a.nrm = c->nrm[gnew]; a.pos = c->pos; a.gbuf = g;
+            a.nrm = c->nrm[gnew]; a.pos = c->pos[gnew]; a.gbuf = g;
             a.W = c->W; a.H = c->H; a.step = 1 << level;        // level starts at 1 => steps 2,4,8,16,32 (:98,386)
             a.sigma_c = p->sigma_l; a.sigma_n = p->sigma_n; a.sigma_x = p->sigma_x;
             a.blur_variance = p->blur_variance ? 1 : 0;
@@ -394,7 +448,11 @@ extern "C" int svgf_denoise(svgf_ctx *c, void *out_rgb_dev, const void *in_rgb_d
             }
             if (strip) LAUNCH(SVGF_KERNEL_ATROUS, launch_atrous_strip(a, s));
             else       LAUNCH(SVGF_KERNEL_ATROUS, launch_atrous_gather(a, s));
-            if (keep) c->hist = dst;
+            if (hist_final && dst >= 0) c->inflight_mask |= 1u << dst;   // written after the history is final
+            if (keep) {
+                c->hist = dst;
+                if (!mark_hist_final()) { snprintf(c->err, sizeof(c->err), "hipEventRecord failed"); return SVGF_ERR_HIP; }
+            }
             src = dst;
         }
     }

@@ -40,7 +40,7 @@ struct TemporalArgs {
     float color_alpha_min, moment_alpha_min;
 };
 
-hipError_t launch_temporal(const TemporalArgs &a, hipStream_t s);
+hipError_t launch_temporal(const TemporalArgs &a, hipStream_t s, bool single_wave_blocks);
 // non-temporal mode: variance = 10, colour = input, split G-buffer (reference EstimateVariance :320-329 + :370)
 hipError_t launch_prepare(const float *in_rgb, const float *gbuf, float4 *cv, float *nrm, int *gid, float *pos,
                           int W, int H, hipStream_t s);

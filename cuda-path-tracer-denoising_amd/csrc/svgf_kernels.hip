@@ -51,11 +51,12 @@ __device__ __forceinline__ int reproj_valid(const TemporalArgs &a, float qx, flo
     return q;
 }
 
-__global__ __launch_bounds__(SVGF_BLOCK) void k_temporal(TemporalArgs a)
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_temporal(TemporalArgs a)
 {
 #pragma clang fp contract(off)
     const int n = a.W * a.H;
-    const int p = blockIdx.x * SVGF_BLOCK + threadIdx.x;
+    const int p = blockIdx.x * BLOCK + threadIdx.x;
     if (p >= n) return;
 
     const float *t = a.gbuf + 13 * (size_t)p;
@@ -148,10 +149,13 @@ __global__ __launch_bounds__(SVGF_BLOCK) void k_temporal(TemporalArgs a)
     a.cv_acc[p] = make_float4(cr, cg, cb, 100.0f);
 }
 
-hipError_t launch_temporal(const TemporalArgs &a, hipStream_t s)
+hipError_t launch_temporal(const TemporalArgs &a, hipStream_t s, bool single_wave_blocks)
 {
     const long long n = (long long)a.W * a.H;
-    hipLaunchKernelGGL(k_temporal, dim3(div_up(n, SVGF_BLOCK)), dim3(SVGF_BLOCK), 0, s, a);
+    // When this pass runs beside an a-trous launch (cross-frame overlap) only single free wave slots exist on a CU:
+    // one-wave workgroups can be placed in them, four-wave workgroups cannot.
+    if (single_wave_blocks) hipLaunchKernelGGL(k_temporal<64>, dim3(div_up(n, 64)), dim3(64), 0, s, a);
+    else hipLaunchKernelGGL(k_temporal<SVGF_BLOCK>, dim3(div_up(n, SVGF_BLOCK)), dim3(SVGF_BLOCK), 0, s, a);
     return hipGetLastError();
 }
 

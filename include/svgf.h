@@ -76,7 +76,10 @@ typedef struct SvgfParams {
     int   right_view_option;  /* ui_right_view_option (0): 0 image, 1 history length, 2 variance */
     /* --- extensions; 0 == reference behaviour --- */
     int   kernel_variant;     /* 0 auto (fastest), 1 strict gather kernel, 2 LDS strip kernel */
-    int   reserved[3];
+    int   inputs_ready;       /* 1: in_rgb/gbuffer are complete when svgf_denoise is CALLED (no producer still pending on
+                                 `stream`).  Lets the temporal pass of this frame run on an internal stream concurrently
+                                 with the previous frame's trailing a-trous levels.  0: everything is ordered on `stream`. */
+    int   reserved[2];
 } SvgfParams;
 
 #define SVGF_MAX_LEVELS 10

@@ -16,7 +16,7 @@ def header_functions():
 
 
 def test_header_symbols_exported(pkg):
-    lib = ctypes.CDLL(pkg.binding.LIB_PATH)
+    lib = pkg.load_library()
     names = header_functions()
     assert len(names) >= 16
     for n in names:
@@ -38,7 +38,7 @@ def test_params_default_matches_reference_ui_defaults(pkg):
     p = pkg.SvgfParams()
     assert lib.svgf_params_default(ctypes.byref(p)) == 0
     q = pkg.reference_defaults()        # reference src/main.cpp:49-62
-    for name, _ in pkg.SvgfParams._fields_[:14]:
+    for name, _ in pkg.SvgfParams._fields_[:15]:
         assert getattr(p, name) == pytest.approx(getattr(q, name)), name
     assert lib.svgf_version() == (0 << 16) | 1
 
