@@ -47,6 +47,8 @@ hipError_t launch_prepare(const float *in_rgb, const float *gbuf, float4 *cv, fl
 hipError_t launch_atrous_gather(const AtrousArgs &a, hipStream_t s);   // strict one-thread-per-pixel gather kernel
 hipError_t launch_atrous_strip(const AtrousArgs &a, hipStream_t s);    // LDS strip-marching kernel (fast path)
 bool       atrous_strip_supported(const AtrousArgs &a);
+hipError_t launch_atrous_share(const AtrousArgs &a, hipStream_t s);    // strip kernel with shared geometric weights (steps 2,4,8)
+bool       atrous_share_supported(const AtrousArgs &a);
 // out = float(value)/scale broadcast to rgb (reference DebugView :331-340)
 hipError_t launch_debug_hlen(const int *hlen, float *out_rgb, int n, float scale, hipStream_t s);
 hipError_t launch_debug_var(const float4 *cv, float *out_rgb, int n, float scale, hipStream_t s);
