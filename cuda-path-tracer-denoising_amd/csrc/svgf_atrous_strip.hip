@@ -124,7 +124,9 @@ __device__ __forceinline__ constexpr float neg_log2_binom(int i)
     return (i == 0) ? 1.4150374992788437f : ((i == 1 || i == -1) ? 2.0f : 4.0f);
 }
 
-template <int LOG2S, int TX, int ROWS>
+// HASVAR = false: the level's filtered variance is not needed (last level, no colour-history copy): the two variance
+// accumulators (sum w^2, sum w^2 var) and the w*w product drop out of every tap.
+template <int LOG2S, int TX, int ROWS, bool HASVAR>
 __global__ __launch_bounds__(TX * ROWS + loader_threads(TX)) void k_atrous_strip(AtrousArgs a, StripGeom gm)
 {
     constexpr int S = 1 << LOG2S;
@@ -412,12 +414,18 @@ __global__ __launch_bounds__(TX * ROWS + loader_threads(TX)) void k_atrous_strip
 #pragma unroll
                     for (int i = 0; i < 5; i++) {
                         if (i == 2 && j == 0) continue;
-                        v2f wv;
-                        wv.x = w[i];
-                        wv.y = w[i] * w[i];
-                        acc.ww += wv;
-                        acc.rg = __builtin_elementwise_fma(Cc[i].xy, v2f{w[i], w[i]}, acc.rg);
-                        acc.bv = __builtin_elementwise_fma(Cc[i].zw, wv, acc.bv);
+                        if (HASVAR) {
+                            v2f wv;
+                            wv.x = w[i];
+                            wv.y = w[i] * w[i];
+                            acc.ww += wv;
+                            acc.rg = __builtin_elementwise_fma(Cc[i].xy, v2f{w[i], w[i]}, acc.rg);
+                            acc.bv = __builtin_elementwise_fma(Cc[i].zw, wv, acc.bv);
+                        } else {
+                            acc.ww.x += w[i];
+                            acc.rg = __builtin_elementwise_fma(Cc[i].xy, v2f{w[i], w[i]}, acc.rg);
+                            acc.bv.x = fmaf(Cc[i].z, w[i], acc.bv.x);
+                        }
                     }
                     if (j < 2) {
 #pragma unroll
@@ -440,7 +448,7 @@ __global__ __launch_bounds__(TX * ROWS + loader_threads(TX)) void k_atrous_strip
             if (wsum > 1e-5f) {                                     // NaN -> false -> pass-through (:159-164)
                 const float rw = __builtin_amdgcn_rcpf(wsum);
                 o0 = c0 * rw; o1 = c1 * rw; o2 = c2 * rw;
-                ov = vsum * __builtin_amdgcn_rcpf(w2sum);
+                ov = HASVAR ? vsum * __builtin_amdgcn_rcpf(w2sum) : 0.0f;
             } else {
                 o0 = C.x; o1 = C.y; o2 = C.z; ov = C.w;
             }
@@ -458,14 +466,14 @@ __global__ __launch_bounds__(TX * ROWS + loader_threads(TX)) void k_atrous_strip
     }
 }
 
-template <int LOG2S, int TX, int ROWS>
+template <int LOG2S, int TX, int ROWS, bool HASVAR>
 hipError_t launch_cfg(const AtrousArgs &a, hipStream_t s)
 {
     constexpr int S = 1 << LOG2S, RW = TX + 4 * S, R = 4 + 2 * ROWS, BW = TX + 2;
     const size_t lds = (size_t)R * RW * 48 + (size_t)2 * ROWS * 2 * BW * 4 + 16;
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_atrous_strip<LOG2S, TX, ROWS>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_atrous_strip<LOG2S, TX, ROWS, HASVAR>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         attr_done = true;
@@ -512,7 +520,7 @@ hipError_t launch_cfg(const AtrousArgs &a, hipStream_t s)
     gm.kx = (float)(1.4426950408889634 / ((double)a.sigma_x + 1e-6));
     const int groups_pad = (gm.n_groups + 7) / 8 * 8;
     const int nblocks = groups_pad * gm.n_strips;
-    hipLaunchKernelGGL((k_atrous_strip<LOG2S, TX, ROWS>), dim3(nblocks), dim3(TX * ROWS + kLoaderThreads), lds, s, a, gm);
+    hipLaunchKernelGGL((k_atrous_strip<LOG2S, TX, ROWS, HASVAR>), dim3(nblocks), dim3(TX * ROWS + kLoaderThreads), lds, s, a, gm);
     if (dbg_env) {
         static int prints = 0;
         (void)hipStreamSynchronize(s);
@@ -562,7 +570,7 @@ bool atrous_strip_supported(const AtrousArgs &a)
     return true;
 }
 
-#define STRIP_CASE(L, T, Rr) if (log2s == L && tx == T && rows == Rr) return launch_cfg<L, T, Rr>(a, s);
+#define STRIP_CASE(L, T, Rr) if (log2s == L && tx == T && rows == Rr) return a.dst ? launch_cfg<L, T, Rr, true>(a, s) : launch_cfg<L, T, Rr, false>(a, s);
 
 hipError_t launch_atrous_strip(const AtrousArgs &a, hipStream_t s)
 {
