@@ -101,6 +101,32 @@ def test_sequences_match_oracle_including_state(pkg, orc, cfg, variant):
     d.free(); o.free()
 
 
+def test_randomised_parameter_sweep_matches_oracle(pkg, orc):
+    """24 seeded random configurations (size, every SvgfParams field, camera motion, mode switches between frames)."""
+    rng = np.random.default_rng(20260928)
+    for case in range(24):
+        W, H = int(rng.integers(1, 400)), int(rng.integers(1, 260))
+        nframes = int(rng.integers(1, 5))
+        moving = bool(rng.integers(0, 2))
+        base = dict(color_alpha=float(rng.uniform(0.02, 1.0)), moment_alpha=float(rng.uniform(0.02, 1.0)),
+                    blur_variance=int(rng.integers(0, 2)), sigma_l=float(rng.uniform(0.05, 4.0)),
+                    sigma_x=float(rng.uniform(0.05, 2.0)), sigma_n=float(rng.uniform(0.02, 1.0)),
+                    atrous_nlevel=int(rng.integers(0, 8)), sepcolor=int(rng.integers(0, 2)), addcolor=int(rng.integers(0, 2)))
+        base["history_level"] = int(rng.integers(0, base["atrous_nlevel"] + 2))
+        d = pkg.Denoiser(W, H, 0)
+        o = orc.Oracle(pkg, W, H, threads=8)
+        for f in range(nframes):
+            p = pkg.reference_defaults().set(temporal_enable=int(rng.integers(0, 2)), spatial_enable=int(rng.integers(0, 4) > 0),
+                                             right_view_option=int(rng.choice([0, 0, 0, 1, 2])), **base)
+            c, g, cam = pkg.synth.render_frame(W, H, f, seed=1000 + case, moving=moving)
+            got = d.denoise_host(c, g, cam, p)
+            ref = o.denoise(c, g, cam, p)
+            e = relerr(got, ref)
+            assert e.max() <= TOL_STRIP * (f + 1), f"case {case} ({W}x{H}) frame {f}: {e.max():.3e} params {base}"
+            assert np.array_equal(d.read_state(0), o.read_state(0)), f"case {case} frame {f}: history length"
+        d.free(); o.free()
+
+
 def test_1080p_full_svgf_matches_oracle(pkg, orc):
     """BASELINE config 2 size.  The oracle takes a few seconds per frame on 16 threads."""
     W, H = 1920, 1080
