@@ -75,7 +75,7 @@ def main():
     if world != a.gpus and world > 1:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("SVGF_BENCH_FORCE_DIST"):   # the env var exercises the RCCL path with one rank
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
@@ -89,7 +89,11 @@ def main():
     if a.config == "4k-static":
         W, H = 3840, 2160
     moving = (a.config == "1080p-moving")
-    ge.build()
+    # one rank per node builds (normally a no-op: the libraries are prebuilt in-tree); the others wait
+    if local_rank == 0:
+        ge.build()
+    if dist is not None:
+        dist.barrier()
     pkg = ge.load_package()
     params = pkg.reference_defaults().set(temporal_enable=1, spatial_enable=1, atrous_nlevel=NLEVEL, history_level=1,
                                           inputs_ready=1)   # inputs are resident in HBM before each call

@@ -43,7 +43,9 @@ def build_hip(force: bool = False) -> str:
     deps = srcs + [os.path.join(CSRC, "svgf_kernels.h"), os.path.join(ROOT, "include", "svgf.h")]
     if not force and _newer(LIB, deps):
         return LIB
-    _run([hipcc_path()] + HIPCC_FLAGS + srcs + ["-o", LIB])
+    tmp = LIB + f".tmp{os.getpid()}"
+    _run([hipcc_path()] + HIPCC_FLAGS + srcs + ["-o", tmp])
+    os.replace(tmp, LIB)              # atomic: concurrent ranks never see a half-written library
     return LIB
 
 
@@ -53,7 +55,9 @@ def build_oracle(force: bool = False) -> str:
     deps = [src, os.path.join(ORACLE_DIR, "svgf_oracle.h"), os.path.join(ROOT, "include", "svgf.h")]
     if not force and _newer(ORACLE_LIB, deps):
         return ORACLE_LIB
-    _run(["gcc", "-O2", "-ffp-contract=off", "-fopenmp", "-shared", "-fPIC", "-std=c11", "-Wall", src, "-o", ORACLE_LIB, "-lm"])
+    tmp = ORACLE_LIB + f".tmp{os.getpid()}"
+    _run(["gcc", "-O2", "-ffp-contract=off", "-fopenmp", "-shared", "-fPIC", "-std=c11", "-Wall", src, "-o", tmp, "-lm"])
+    os.replace(tmp, ORACLE_LIB)
     return ORACLE_LIB
 
 
