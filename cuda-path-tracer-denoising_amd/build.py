@@ -44,7 +44,8 @@ def build_hip(force: bool = False) -> str:
     if not force and _newer(LIB, deps):
         return LIB
     tmp = LIB + f".tmp{os.getpid()}"
-    _run([hipcc_path()] + HIPCC_FLAGS + srcs + ["-o", tmp])
+    extra = os.environ.get("SVGF_EXTRA_HIPCC_FLAGS", "").split()      # kernel experiments only (tools/, profiles/)
+    _run([hipcc_path()] + HIPCC_FLAGS + extra + srcs + ["-o", tmp])
     os.replace(tmp, LIB)              # atomic: concurrent ranks never see a half-written library
     return LIB
 

@@ -42,8 +42,17 @@
 namespace {
 
 constexpr float kLog2e = 1.44269504088896340736f;
-constexpr int kLoaderGroups = 3;                                // groups take turns: issue / in flight / commit
-__host__ __device__ constexpr int loader_group(int tx) { return tx / 2; }            // threads per loader group
+#ifndef SVGF_LOADER_GROUPS
+#define SVGF_LOADER_GROUPS 2
+#endif
+#ifndef SVGF_LOADER_DIV
+#define SVGF_LOADER_DIV 2
+#endif
+#ifndef SVGF_STRIP_ATTR
+#define SVGF_STRIP_ATTR
+#endif
+constexpr int kLoaderGroups = SVGF_LOADER_GROUPS;               // groups take turns: issue / in flight / commit
+__host__ __device__ constexpr int loader_group(int tx) { return tx / SVGF_LOADER_DIV; }   // threads per loader group
 __host__ __device__ constexpr int loader_threads(int tx) { return kLoaderGroups * loader_group(tx); }
 
 struct StripGeom {
@@ -127,7 +136,7 @@ __device__ __forceinline__ constexpr float neg_log2_binom(int i)
 // HASVAR = false: the level's filtered variance is not needed (last level, no colour-history copy): the two variance
 // accumulators (sum w^2, sum w^2 var) and the w*w product drop out of every tap.
 template <int LOG2S, int TX, int ROWS, bool HASVAR>
-__global__ __launch_bounds__(TX * ROWS + loader_threads(TX)) void k_atrous_strip(AtrousArgs a, StripGeom gm)
+__global__ __launch_bounds__(TX * ROWS + loader_threads(TX)) SVGF_STRIP_ATTR void k_atrous_strip(AtrousArgs a, StripGeom gm)
 {
     constexpr int S = 1 << LOG2S;
     constexpr int RW = TX + 4 * S;          // staged pixels per lattice row
@@ -236,8 +245,10 @@ __global__ __launch_bounds__(TX * ROWS + loader_threads(TX)) void k_atrous_strip
     // Loader groups: kLoaderGroups groups of kLoaderGroup threads; group q owns the rows that iterations j with
     // j % kLoaderGroups == q newly need.  A group issues its loads at the start of iteration j-kLoaderGroups, keeps
     // them in flight across kLoaderGroups-1 barriers, converts and stores them during iteration j-1, and the barrier
-    // ending j-1 publishes them: every global load has kLoaderGroups-1 whole iterations (~2 x 3.5 us) to land — at 4K
-    // the planes no longer sit in the Infinity Cache and one iteration was not enough (profiles/r01_strip_timeline_4k.log).
+    // ending j-1 publishes them: every global load has kLoaderGroups-1 whole iterations (~3.5 us each) to land.
+    // Two groups (12 waves per workgroup = 3 per SIMD) beat three (14 waves): the level itself is as fast or faster,
+    // and each SIMD keeps 128 VGPRs free, which is what lets the next frame's temporal pass (48 VGPRs, side stream)
+    // become co-resident in useful numbers (profiles/r01_exp_loader_groups.log: +4..6 % whole-frame at 1080p and 4K).
     constexpr int ML = (ROWS * RW + kLoaderGroup - 1) / kLoaderGroup;
     constexpr int MBL = (ROWS * 2 * BW + kLoaderGroup - 1) / kLoaderGroup;
     const bool is_loader = (tid >= NC);
