@@ -39,7 +39,7 @@ namespace {
 
 constexpr float kLog2e = 1.44269504088896340736f;
 constexpr int TX = 256, ROWS = 2;
-constexpr int kLoaderGroups = 3, kLoaderGroup = 128, kLoaderThreads = kLoaderGroups * kLoaderGroup;
+constexpr int kLoaderGroups = 2, kLoaderGroup = 128, kLoaderThreads = kLoaderGroups * kLoaderGroup;
 constexpr int NC = TX * ROWS, NT = NC + kLoaderThreads;
 constexpr int RG = 6, RK = 8, RT = 4, NF = 12;
 
@@ -49,6 +49,8 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 struct ShareGeom {
     int n_strips, n_segs, seg_rows, n_groups;
     float kn, kx;
+    unsigned long long *dbg;   // tuning only (SVGF_SHARE_DBG): per-phase s_memtime stamps of one workgroup
+    int dbg_block;
 };
 
 struct Px {
@@ -112,6 +114,11 @@ __global__ __launch_bounds__(NT) void k_atrous_share(AtrousArgs a, ShareGeom gm)
     const int x0 = strip * TX;
     const int tid = threadIdx.x;
     if (tid == 0) *nan_seen = 0;
+    int dbg_it = 0;
+    auto stamp = [&](int phase_id) {
+        if (gm.dbg && bid == gm.dbg_block && (tid & 63) == 0 && dbg_it < 16)
+            gm.dbg[((tid >> 6) * 16 + dbg_it) * 8 + phase_id] = __builtin_amdgcn_s_memtime();
+    };
 
     // ring slots of lattice row br, given rel = br - (b0 - 2) >= 0
     auto slotG = [&](int rel) { return rel % RG; };
@@ -186,8 +193,7 @@ __global__ __launch_bounds__(NT) void k_atrous_share(AtrousArgs a, ShareGeom gm)
     // HALO = true (loader threads, halo columns): partner columns are clamped into the staged row (their entries
     // are never read), which costs per-tap address arithmetic; compute threads never need it.
     auto wrap = [](int v, int n) { return v >= n ? v - n : (v < 0 ? v + n : v); };   // v in (-n, 2n)
-    auto pass_g = [&](auto careful_tag, auto halo_tag, int rel, int xi) {
-        float tF[NF];
+    auto pass_g = [&](auto careful_tag, auto halo_tag, int rel, int xi, float (&tF)[NF]) {
         constexpr bool CAREFUL = decltype(careful_tag)::value;
         constexpr bool HALO = decltype(halo_tag)::value;
         int rowA[3], rowB[3];
@@ -232,17 +238,15 @@ __global__ __launch_bounds__(NT) void k_atrous_share(AtrousArgs a, ShareGeom gm)
                 float t = fmaf(n_, kn, neg_log2_binom(fwd_i(f)) + neg_log2_binom(fwd_j(f)));
                 tF[f] = fmaf(x_, kx, t);
             }
-            asm volatile("" ::: "memory");           // keep the second batch's LDS loads behind the first batch's math
-            __builtin_amdgcn_sched_barrier(0);
         }
         // T[slot][f][column]: a backward reader takes one f at consecutive columns -> conflict-free ds_read_b32
         char *trow = smem + L::T + (slotT(rel) * NF * RW + xi) * 4;
 #pragma unroll
         for (int f = 0; f < NF; f++) *reinterpret_cast<float *>(trow + f * RW * 4) = tF[f];
     };
-    auto pass_g_dispatch = [&](auto halo_tag, int rel, int xi) {
-        if (*nan_seen != 0) pass_g(std::true_type{}, halo_tag, rel, xi);
-        else pass_g(std::false_type{}, halo_tag, rel, xi);
+    auto pass_g_dispatch = [&](auto halo_tag, int rel, int xi, float (&tF)[NF]) {
+        if (*nan_seen != 0) pass_g(std::true_type{}, halo_tag, rel, xi, tF);
+        else pass_g(std::false_type{}, halo_tag, rel, xi, tF);
     };
 
     // ---------------- loader bookkeeping (identical scheme to the strip kernel) ----------------
@@ -282,7 +286,8 @@ __global__ __launch_bounds__(NT) void k_atrous_share(AtrousArgs a, ShareGeom gm)
     if (is_loader && lgroup >= 1) loader_issue(lgroup);
     __syncthreads();
     {
-        if (tid < 2 * RW) pass_g_dispatch(std::true_type{}, tid / RW, tid % RW);   // rel 0,1 = rows b0-2, b0-1, every column
+        float tdrop[NF];
+        if (tid < 2 * RW) pass_g_dispatch(std::true_type{}, tid / RW, tid % RW, tdrop);   // rel 0,1 = rows b0-2, b0-1, every column
     }
     __syncthreads();
 
@@ -290,7 +295,8 @@ __global__ __launch_bounds__(NT) void k_atrous_share(AtrousArgs a, ShareGeom gm)
         // ================================ loader waves ================================
         __builtin_amdgcn_s_setprio(3);
         int it = 0;
-        for (int bc = b0; bc < b1; bc += ROWS, it++) {
+        for (int bc = b0; bc < b1; bc += ROWS, it++, dbg_it++) {
+            stamp(0);
             if ((it + 1) % kLoaderGroups == lgroup) loader_commit(it + 1);
             else if (it % kLoaderGroups == lgroup) {
                 // the group whose turn it is to issue first computes the forward terms of the 2S halo columns left and
@@ -298,12 +304,18 @@ __global__ __launch_bounds__(NT) void k_atrous_share(AtrousArgs a, ShareGeom gm)
                 if (llane < 8 * S) {
                     const int rr = llane / (4 * S), hc = llane % (4 * S);
                     const int xi = hc < 2 * S ? hc : (TX + hc);             // [0,2S) and [TX+2S, RW)
-                    pass_g_dispatch(std::true_type{}, bc - (b0 - 2) + rr, xi);
+                    float tdrop[NF];
+                    pass_g_dispatch(std::true_type{}, bc - (b0 - 2) + rr, xi, tdrop);
                 }
                 loader_issue(it + kLoaderGroups);
             }
+            stamp(1);
+#ifndef SVGF_SHARE_HACK_NO_A
             __syncthreads();     // A: T published
+#endif
+            stamp(2);
             __syncthreads();     // B: pass C done, new rows committed
+            stamp(3);
         }
         return;
     }
@@ -313,102 +325,189 @@ __global__ __launch_bounds__(NT) void k_atrous_share(AtrousArgs a, ShareGeom gm)
     const int tx = tid - r * TX;
     const int x = x0 + tx;
     const int xi = tx + 2 * S;
-    int it = 0;
-    for (int bc = b0; bc < b1; bc += ROWS, it++) {
+    // One iteration of a compute thread is a software pipeline of six stages whose LDS reads are issued one stage ahead
+    // of their arithmetic (sched_barrier(0) pins the stage boundaries; registers: two batches of 6 partners in flight):
+    //   G0 G1   forward terms of partners 0-5 / 6-11 (geometry rows rel .. rel+2)      -> tF[] and the T ring
+    //   F0 F1   colour part of the 12 FORWARD taps, t from tF[] (no other thread's data)
+    //   ---- barrier A: every T entry of rows bc-2 .. bc+1 is published ----
+    //   B0 B1   colour part of the 12 BACKWARD taps, t = the partner's T entry
+    struct GBatch { v4f A[6]; v2f B[6]; };
+    struct CBatch { v4f C[6]; float l[6]; };
+    auto body = [&](auto careful_tag, int bc, int it) {
+        constexpr bool CAREFUL = decltype(careful_tag)::value;
         const int bo = bc + r;
         const int rel = bo - (b0 - 2);
-        pass_g_dispatch(std::false_type{}, rel, xi);
-        __syncthreads();     // A
+        const bool live = (bo < b1 && x < W);
+        const int y = phase + (bo << LOG2S);
+        stamp(0);
 
-        if (bo < b1 && x < W) {
-            const int y = phase + (bo << LOG2S);
-            const int ock = slotK(rel) * RW + xi;   // (recomputed below as a base; the compiler folds them)
-            const float4 C = *reinterpret_cast<const float4 *>(smem + L::KC + ock * 16);
-            const float lp = *reinterpret_cast<const float *>(smem + L::KL + ock * 4);
-
-            float var = C.w;
-            if (a.blur_variance) {
-                const float *bl = blur + (it & 1) * (ROWS * 2 * BW) + r * (2 * BW) + tx;
-                const float m0 = bl[0], m1 = bl[1], m2 = bl[2];
-                const float p0 = bl[BW], p1 = bl[BW + 1], p2 = bl[BW + 2];
-                const float c0v = reinterpret_cast<const float4 *>(smem + L::KC)[ock - 1].w;
-                const float c2v = reinterpret_cast<const float4 *>(smem + L::KC)[ock + 1].w;
-                const float wr_m = (y - 1 >= 0) ? 0.25f : 0.0f, wr_p = (y + 1 < H) ? 0.25f : 0.0f;
-                const float wc_l = (x - 1 >= 0) ? 0.25f : 0.0f, wc_r = (x + 1 < W) ? 0.25f : 0.0f;
-                const float col_l = wr_m * m0 + 0.5f * c0v + wr_p * p0;
-                const float col_c = wr_m * m1 + 0.5f * C.w + wr_p * p1;
-                const float col_r = wr_m * m2 + 0.5f * c2v + wr_p * p2;
-                const float sum = wc_l * col_l + 0.5f * col_c + wc_r * col_r;
-                const float sumw = (wr_m + 0.5f + wr_p) * (wc_l + 0.5f + wc_r);
-                var = sum * __builtin_amdgcn_rcpf(sumw);
+        // row bases (one modulo each); every tap address is base + compile-time offset
+        int ga[3], gb[3], kcb[5], klb[5], tb[3];
+        const int sg = slotG(rel), sk = slotK(rel), st = slotT(rel);
+#pragma unroll
+        for (int jj = 0; jj < 3; jj++) {
+            const int o = wrap(sg + jj, RG) * RW + xi;
+            ga[jj] = L::GA + o * 16;
+            gb[jj] = L::GB + o * 8;
+            tb[jj] = L::T + (wrap(st - jj, RT) * NF * RW + xi) * 4;
+        }
+#pragma unroll
+        for (int jj = 0; jj < 5; jj++) {
+            const int o = wrap(sk + jj - 2, RK) * RW + xi;
+            kcb[jj] = L::KC + o * 16;
+            klb[jj] = L::KL + o * 4;
+        }
+        auto g_load = [&](auto half_tag, GBatch &b) {
+            constexpr int HALF = decltype(half_tag)::value;
+#pragma unroll
+            for (int k = 0; k < 6; k++) {
+                const int f = HALF * 6 + k;
+                b.A[k] = *reinterpret_cast<const v4f *>(smem + ga[fwd_j(f)] + fwd_i(f) * S * 16);
+                b.B[k] = *reinterpret_cast<const v2f *>(smem + gb[fwd_j(f)] + fwd_i(f) * S * 8);
             }
-            var = fmaxf(var, 0.0f);
-            const float kl = kLog2e * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(var) * a.sigma_c + 1e-6f);
-
-            // centre tap: weight exactly h = 9/64
-            constexpr float w0 = 0.140625f;
-            v2f acc_ww = v2f{w0, w0 * w0};
-            v2f acc_rg = v2f{w0 * C.x, w0 * C.y};
-            v2f acc_bv = v2f{w0 * C.z, (w0 * w0) * C.w};
-
-            // row bases (one modulo each); every tap address is base + compile-time offset
-            int kcb[5], klb[5], tb[3];
-            const int sk = slotK(rel), st = slotT(rel);
+        };
+        auto c_load = [&](auto back_tag, auto half_tag, CBatch &b) {
+            constexpr bool BACK = decltype(back_tag)::value;
+            constexpr int HALF = decltype(half_tag)::value;
 #pragma unroll
-            for (int jj = 0; jj < 5; jj++) {
-                const int o = wrap(sk + jj - 2, RK) * RW + xi;
-                kcb[jj] = L::KC + o * 16;
-                klb[jj] = L::KL + o * 4;
+            for (int k = 0; k < 6; k++) {
+                const int f = HALF * 6 + k;
+                const int di = BACK ? -fwd_i(f) : fwd_i(f), dj = BACK ? -fwd_j(f) : fwd_j(f);
+                b.C[k] = *reinterpret_cast<const v4f *>(smem + kcb[dj + 2] + di * S * 16);
+                b.l[k] = *reinterpret_cast<const float *>(smem + klb[dj + 2] + di * S * 4);
             }
-#pragma unroll
-            for (int jj = 0; jj < 3; jj++) tb[jj] = L::T + (wrap(st - jj, RT) * NF * RW + xi) * 4;
+        };
 
-            // colour part of one batch of 6 taps: e = kl*|dl| + t, w = 2^-e, accumulate.  BACK selects the backward taps.
-            auto colour_batch = [&](auto back_tag, auto half_tag) {
-                constexpr bool BACK = decltype(back_tag)::value;
-                constexpr int HALF = decltype(half_tag)::value;
-                v4f Cq[6];
-                float lq[6], tt[6];
-#pragma unroll
-                for (int k = 0; k < 6; k++) {
-                    const int f = HALF * 6 + k;
-                    const int di = BACK ? -fwd_i(f) : fwd_i(f), dj = BACK ? -fwd_j(f) : fwd_j(f);
-                    Cq[k] = *reinterpret_cast<const v4f *>(smem + kcb[dj + 2] + di * S * 16);
-                    lq[k] = *reinterpret_cast<const float *>(smem + klb[dj + 2] + di * S * 4);
-                    // backward: partner q = p - (i*S, j rows) published the term as its forward entry f
-                    // forward: this pixel's own entry f;  backward: the entry f of partner q = p - (i*S, j rows)
-                    tt[k] = BACK ? *reinterpret_cast<const float *>(smem + tb[fwd_j(f)] + (f * RW - fwd_i(f) * S) * 4)
-                                 : *reinterpret_cast<const float *>(smem + tb[0] + f * RW * 4);
-                }
-                float w[6];
-#pragma unroll
-                for (int k = 0; k < 6; k++) w[k] = fmaf(fabsf(lq[k] - lp), kl, tt[k]);
-                __builtin_amdgcn_sched_barrier(0x100);
-#pragma unroll
-                for (int k = 0; k < 6; k++) w[k] = __builtin_amdgcn_exp2f(-w[k]);
-                __builtin_amdgcn_sched_barrier(0x100);
-#pragma unroll
-                for (int k = 0; k < 6; k++) {
-                    v2f wv;
-                    wv.x = w[k];
-                    wv.y = w[k] * w[k];
-                    acc_ww += wv;
-                    acc_rg = __builtin_elementwise_fma(Cq[k].xy, v2f{w[k], w[k]}, acc_rg);
-                    acc_bv = __builtin_elementwise_fma(Cq[k].zw, wv, acc_bv);
-                }
-                asm volatile("" ::: "memory");       // one batch in flight at a time (register budget)
-                __builtin_amdgcn_sched_barrier(0);
-            };
-            colour_batch(std::false_type{}, std::integral_constant<int, 0>{});
-            colour_batch(std::false_type{}, std::integral_constant<int, 1>{});
-            colour_batch(std::true_type{}, std::integral_constant<int, 0>{});
-            colour_batch(std::true_type{}, std::integral_constant<int, 1>{});
+        // ---- issue: centre geometry + both G batches ----
+        GBatch g0, g1;
+        const v4f Ac = *reinterpret_cast<const v4f *>(smem + ga[0]);
+        const v2f Bc = *reinterpret_cast<const v2f *>(smem + gb[0]);
+        g_load(std::integral_constant<int, 0>{}, g0);
+        const float4 C = *reinterpret_cast<const float4 *>(smem + kcb[2]);
+        const float lp = *reinterpret_cast<const float *>(smem + klb[2]);
 
-            const float c0 = acc_rg.x, c1 = acc_rg.y, c2 = acc_bv.x, vsum = acc_bv.y, wsum = acc_ww.x, w2sum = acc_ww.y;
+        // centre variance: 3x3 gaussian with out-of-image taps dropped and renormalised (:102-118)
+        float var = C.w;
+        if (a.blur_variance) {
+            const float *bl = blur + (it & 1) * (ROWS * 2 * BW) + r * (2 * BW) + tx;
+            const float m0 = bl[0], m1 = bl[1], m2 = bl[2];
+            const float p0 = bl[BW], p1 = bl[BW + 1], p2 = bl[BW + 2];
+            const float c0v = *reinterpret_cast<const float *>(smem + kcb[2] - 16 + 12);
+            const float c2v = *reinterpret_cast<const float *>(smem + kcb[2] + 16 + 12);
+            const float wr_m = (y - 1 >= 0) ? 0.25f : 0.0f, wr_p = (y + 1 < H) ? 0.25f : 0.0f;
+            const float wc_l = (x - 1 >= 0) ? 0.25f : 0.0f, wc_r = (x + 1 < W) ? 0.25f : 0.0f;
+            const float col_l = wr_m * m0 + 0.5f * c0v + wr_p * p0;
+            const float col_c = wr_m * m1 + 0.5f * C.w + wr_p * p1;
+            const float col_r = wr_m * m2 + 0.5f * c2v + wr_p * p2;
+            const float sum = wc_l * col_l + 0.5f * col_c + wc_r * col_r;
+            const float sumw = (wr_m + 0.5f + wr_p) * (wc_l + 0.5f + wc_r);
+            var = sum * __builtin_amdgcn_rcpf(sumw);
+        }
+        var = fmaxf(var, 0.0f);
+        const float kl = kLog2e * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(var) * a.sigma_c + 1e-6f);
+        // centre tap: weight exactly h = 9/64
+        constexpr float w0 = 0.140625f;
+        v2f acc_ww = v2f{w0, w0 * w0};
+        v2f acc_rg = v2f{w0 * C.x, w0 * C.y};
+        v2f acc_bv = v2f{w0 * C.z, (w0 * w0) * C.w};
+
+        float tF[NF];
+        const v2f c0 = Ac.xy, c1 = Ac.zw;
+        auto g_math = [&](auto half_tag, const GBatch &b) {
+            constexpr int HALF = decltype(half_tag)::value;
+            v2f s2[6];
+#pragma unroll
+            for (int k = 0; k < 6; k++) {
+                const v2f d0 = b.A[k].xy - c0, d1 = b.A[k].zw - c1, d2 = b.B[k] - Bc;
+                v2f t = d0 * d0;
+                t = __builtin_elementwise_fma(d1, d1, t);
+                s2[k] = __builtin_elementwise_fma(d2, d2, t);
+            }
+            __builtin_amdgcn_sched_barrier(0x100);
+            float dn[6], dx[6];
+#pragma unroll
+            for (int k = 0; k < 6; k++) {
+                dn[k] = __builtin_amdgcn_sqrtf(s2[k].x);
+                dx[k] = __builtin_amdgcn_sqrtf(s2[k].y);
+            }
+            __builtin_amdgcn_sched_barrier(0x100);
+#pragma unroll
+            for (int k = 0; k < 6; k++) {
+                const int f = HALF * 6 + k;
+                float n_ = dn[k], x_ = dx[k];
+                if (CAREFUL) { n_ = fmaxf(n_, 0.0f); x_ = fmaxf(x_, 0.0f); }     // min(1, exp(-NaN)) == 1 in the reference
+                const float t = fmaf(n_, kn, neg_log2_binom(fwd_i(f)) + neg_log2_binom(fwd_j(f)));
+                tF[f] = fmaf(x_, kx, t);
+            }
+        };
+        auto c_math = [&](const CBatch &b, const float (&tt)[6]) {
+            float w[6];
+#pragma unroll
+            for (int k = 0; k < 6; k++) w[k] = fmaf(fabsf(b.l[k] - lp), kl, tt[k]);
+            __builtin_amdgcn_sched_barrier(0x100);
+#pragma unroll
+            for (int k = 0; k < 6; k++) w[k] = __builtin_amdgcn_exp2f(-w[k]);
+            __builtin_amdgcn_sched_barrier(0x100);
+#pragma unroll
+            for (int k = 0; k < 6; k++) {
+                v2f wv;
+                wv.x = w[k];
+                wv.y = w[k] * w[k];
+                acc_ww += wv;
+                acc_rg = __builtin_elementwise_fma(b.C[k].xy, v2f{w[k], w[k]}, acc_rg);
+                acc_bv = __builtin_elementwise_fma(b.C[k].zw, wv, acc_bv);
+            }
+        };
+
+        CBatch f0, f1, k0, k1;
+        __builtin_amdgcn_sched_barrier(0);
+        g_load(std::integral_constant<int, 1>{}, g1);
+        g_math(std::integral_constant<int, 0>{}, g0);
+        __builtin_amdgcn_sched_barrier(0);
+        c_load(std::false_type{}, std::integral_constant<int, 0>{}, f0);
+        g_math(std::integral_constant<int, 1>{}, g1);
+        __builtin_amdgcn_sched_barrier(0);
+        c_load(std::false_type{}, std::integral_constant<int, 1>{}, f1);
+        {   // T[slot][f][column]: a backward reader takes one f at consecutive columns -> conflict-free ds_read_b32
+            char *trow = smem + tb[0];
+#pragma unroll
+            for (int f = 0; f < NF; f++) *reinterpret_cast<float *>(trow + f * RW * 4) = tF[f];
+        }
+        stamp(1);
+        {
+            const float tt[6] = {tF[0], tF[1], tF[2], tF[3], tF[4], tF[5]};
+            c_math(f0, tt);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        c_load(std::true_type{}, std::integral_constant<int, 0>{}, k0);
+        {
+            const float tt[6] = {tF[6], tF[7], tF[8], tF[9], tF[10], tF[11]};
+            c_math(f1, tt);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        c_load(std::true_type{}, std::integral_constant<int, 1>{}, k1);
+        stamp(2);
+#ifndef SVGF_SHARE_HACK_NO_A
+        __syncthreads();     // A: every T entry of rows bc-2 .. bc+1 is published
+#endif
+        stamp(3);
+
+        // backward: partner q = p - (i*S, j rows) published the term as ITS forward entry f
+        float tb0[6], tb1[6];
+#pragma unroll
+        for (int k = 0; k < 6; k++) {
+            tb0[k] = *reinterpret_cast<const float *>(smem + tb[fwd_j(k)] + (k * RW - fwd_i(k) * S) * 4);
+            tb1[k] = *reinterpret_cast<const float *>(smem + tb[fwd_j(6 + k)] + ((6 + k) * RW - fwd_i(6 + k) * S) * 4);
+        }
+        c_math(k0, tb0);
+        c_math(k1, tb1);
+
+        if (live) {
+            const float o_r = acc_rg.x, o_g = acc_rg.y, o_b = acc_bv.x, vsum = acc_bv.y, wsum = acc_ww.x, w2sum = acc_ww.y;
             float o0, o1, o2, ov;
             if (wsum > 1e-5f) {                                     // NaN -> false -> pass-through (:159-164)
                 const float rw = __builtin_amdgcn_rcpf(wsum);
-                o0 = c0 * rw; o1 = c1 * rw; o2 = c2 * rw;
+                o0 = o_r * rw; o1 = o_g * rw; o2 = o_b * rw;
                 ov = vsum * __builtin_amdgcn_rcpf(w2sum);
             } else {
                 o0 = C.x; o1 = C.y; o2 = C.z; ov = C.w;
@@ -421,7 +520,15 @@ __global__ __launch_bounds__(NT) void k_atrous_share(AtrousArgs a, ShareGeom gm)
             if (a.dst) a.dst[p] = make_float4(o0, o1, o2, ov);
             if (a.out_rgb) { float *o = a.out_rgb + 3u * p; o[0] = o0; o[1] = o1; o[2] = o2; }
         }
-        __syncthreads();     // B
+        stamp(4);
+        __syncthreads();     // B: T rows and ring slots may be overwritten
+        stamp(5);
+    };
+
+    int it = 0;
+    for (int bc = b0; bc < b1; bc += ROWS, it++, dbg_it++) {
+        if (*nan_seen != 0) body(std::true_type{}, bc, it);       // wave-uniform: every thread reads the same LDS word
+        else body(std::false_type{}, bc, it);
     }
 }
 
@@ -464,7 +571,38 @@ hipError_t launch_share_cfg(const AtrousArgs &a, hipStream_t s)
     gm.kx = (float)(1.4426950408889634 / ((double)a.sigma_x + 1e-6));
     const int groups_pad = (gm.n_groups + 7) / 8 * 8;
     const int nblocks = groups_pad * gm.n_strips;
+    gm.dbg = nullptr; gm.dbg_block = 0;
+    static unsigned long long *dbg_buf = nullptr;
+    const char *dbg_env = getenv("SVGF_SHARE_DBG");
+    if (dbg_env) {
+        if (!dbg_buf) (void)hipMalloc((void **)&dbg_buf, 16 * 16 * 8 * sizeof(unsigned long long));
+        (void)hipMemsetAsync(dbg_buf, 0, 16 * 16 * 8 * sizeof(unsigned long long), s);
+        gm.dbg = dbg_buf; gm.dbg_block = atoi(dbg_env);
+    }
     hipLaunchKernelGGL((k_atrous_share<LOG2S>), dim3(nblocks), dim3(NT), lds, s, a, gm);
+    if (dbg_env) {
+        static int prints = 0;
+        (void)hipStreamSynchronize(s);
+        unsigned long long h[16 * 16 * 8];
+        (void)hipMemcpy(h, dbg_buf, sizeof(h), hipMemcpyDeviceToHost);
+        if (prints++ < 6) {
+            const int nw = NT / 64, nlw = kLoaderThreads / 64;
+            fprintf(stderr, "[share dbg] S=%d blocks=%d segs=%d seg_rows=%d lds=%zu waves=%d (last %d = loaders)\n", S, nblocks, gm.n_segs,
+                    gm.seg_rows, lds, nw, nlw);
+            const int show[4] = { 0, nw - nlw - 1, nw - nlw, nw - 1 };
+            for (int si = 0; si < 4; si++) {
+                const int w = show[si];
+                for (int it = 0; it < 16 && h[(w * 16 + it) * 8]; it++) {
+                    unsigned long long *t = &h[(w * 16 + it) * 8];
+                    if (w >= nw - nlw)
+                        fprintf(stderr, "  loader %2d it %2d: t0=%6llu work %6llu barA %5llu barB %5llu\n", w, it, t[0] - h[0], t[1] - t[0], t[2] - t[1], t[3] - t[2]);
+                    else
+                        fprintf(stderr, "  wave %2d it %2d: t0=%6llu G %5llu fwd %5llu barA %5llu bwd+out %5llu barB %5llu\n", w, it, t[0] - h[0],
+                                t[1] - t[0], t[2] - t[1], t[3] - t[2], t[4] - t[3], t[5] - t[4]);
+                }
+            }
+        }
+    }
     return hipGetLastError();
 }
 

@@ -51,6 +51,18 @@ constexpr float kLog2e = 1.44269504088896340736f;
 #ifndef SVGF_STRIP_ATTR
 #define SVGF_STRIP_ATTR
 #endif
+// Wave priorities (s_setprio).  The SIMD arbiter serves the oldest ready wave first, so of the two compute waves that
+// share a SIMD the older one used to finish its iteration ~2000 cycles early and idle at the barrier while the younger
+// ran alone, unable to hide its own latencies (profiles/r01_strip_phase_timeline_v3.log: taps 4300 vs 5650 cycles).
+// With SVGF_PROGRESS_PRIO a compute wave starts every iteration at priority 3 and lowers itself as it completes tap
+// rows: whichever wave is behind outranks the one that is ahead, both finish together, and the iteration shrinks from
+// ~7250 to ~6300 cycles (profiles/r01_exp_progress_prio.log).  Loader waves sit at SVGF_LOADER_PRIO.
+#ifndef SVGF_PROGRESS_PRIO
+#define SVGF_PROGRESS_PRIO 1
+#endif
+#ifndef SVGF_LOADER_PRIO
+#define SVGF_LOADER_PRIO 2
+#endif
 constexpr int kLoaderGroups = SVGF_LOADER_GROUPS;               // groups take turns: issue / in flight / commit
 __host__ __device__ constexpr int loader_group(int tx) { return tx / SVGF_LOADER_DIV; }   // threads per loader group
 __host__ __device__ constexpr int loader_threads(int tx) { return kLoaderGroups * loader_group(tx); }
@@ -68,7 +80,7 @@ struct StripGeom {
 struct Px {   // one staged pixel in registers
     float4 cv;
     float nx, ny, nz, px, py, pz;
-    int lds_off;   // byte offset of its slot in the LDS ring; bit 31 set = out-of-image pixel
+    int lds_off;   // byte offset of its slot in the LDS ring; bit 31 or bit 30 set = out-of-image pixel
 };
 
 __device__ __forceinline__ float lum_f64(float r, float g, float b)
@@ -207,11 +219,11 @@ __global__ __launch_bounds__(TX * ROWS + loader_threads(TX)) SVGF_STRIP_ATTR voi
         const float inf = __builtin_huge_valf();
 #pragma unroll
         for (int m = 0; m < M; m++) {
-            const bool ok = px[m].lds_off >= 0;
+            const bool ok = (unsigned)px[m].lds_off < 0x40000000u;     // bits 31 / 30: row / column outside the image
             const float lum = lum_f64(px[m].cv.x, px[m].cv.y, px[m].cv.z);
             const float mag = fabsf(px[m].nx) + fabsf(px[m].ny) + fabsf(px[m].nz) + fabsf(px[m].px) + fabsf(px[m].py) + fabsf(px[m].pz);
             if (!(mag < inf)) *nan_seen = 1;                    // NaN or inf in a normal / position (rare)
-            char *d = smem + (px[m].lds_off & 0x7fffffff);
+            char *d = smem + (px[m].lds_off & 0x3fffffff);
             *reinterpret_cast<float4 *>(d) = make_float4(px[m].nx, px[m].px, px[m].ny, px[m].py);
             *reinterpret_cast<float4 *>(d + 16) = make_float4(px[m].nz, px[m].pz, ok ? lum : inf, 0.0f);
             *reinterpret_cast<float4 *>(d + 32) = ok ? px[m].cv : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -250,25 +262,106 @@ __global__ __launch_bounds__(TX * ROWS + loader_threads(TX)) SVGF_STRIP_ATTR voi
     // and each SIMD keeps 128 VGPRs free, which is what lets the next frame's temporal pass (48 VGPRs, side stream)
     // become co-resident in useful numbers (profiles/r01_exp_loader_groups.log: +4..6 % whole-frame at 1080p and 4K).
     constexpr int ML = (ROWS * RW + kLoaderGroup - 1) / kLoaderGroup;
-    constexpr int MBL = (ROWS * 2 * BW + kLoaderGroup - 1) / kLoaderGroup;
+    constexpr int NBT = TX / kLoaderGroup;              // blur columns 0 .. TX-1 per thread and (row, side) combination
+    constexpr int NBC = ROWS * 2;                       // combinations c = 2 * (row of the iteration) + (0: y-1 | 1: y+1)
+    static_assert(TX % kLoaderGroup == 0 && NBC * 2 <= kLoaderGroup, "loader mapping");
     const bool is_loader = (tid >= NC);
     const int lgroup = is_loader ? (tid - NC) / kLoaderGroup : -1;
     const int llane = is_loader ? (tid - NC) % kLoaderGroup : 0;
     Px lpx[ML];
-    float lbv[MBL];
+    float lbv[NBC * NBT + 1];
+    // Everything about a loader thread's pixels that does not change from iteration to iteration is computed once:
+    // per pixel an issue then costs two selects, two adds and two address scalings (the lattice row, its clamped
+    // source row and its ring slot are wave-uniform and live in SGPRs); per blur value nothing at all (SGPR row base +
+    // invariant VGPR offset).  The loader waves share the SIMDs with the VALU-bound compute waves, so their
+    // instruction count matters as much as their latency.
+    int l_xq[ML];       // clamped source column
+    int l_lds[ML];      // xi * PXB, bit 30 set if the column lies outside the image
+    bool l_r1[ML];      // pixel belongs to the second row of the iteration (ROWS == 2)
+    int b_voff[NBT];    // byte offset of {clamped column}.w inside a source row
+    bool b_ok[NBT];
+    if (is_loader) {
+#pragma unroll
+        for (int m = 0; m < ML; m++) {
+            const int idx = min(llane + m * kLoaderGroup, ROWS * RW - 1);   // surplus lanes repeat the last pixel
+            const int rr = idx / RW, xi = idx - rr * RW;
+            const int xs = x0 - 2 * S + xi;
+            l_xq[m] = min(max(xs, 0), W - 1);
+            l_lds[m] = (xi * PXB) | ((xs >= 0 && xs < W) ? 0 : 0x40000000);
+            l_r1[m] = (rr != 0);
+        }
+#pragma unroll
+        for (int t = 0; t < NBT; t++) {
+            const int xs = x0 - 1 + llane + t * kLoaderGroup;
+            b_ok[t] = (xs >= 0 && xs < W);
+            b_voff[t] = min(max(xs, 0), W - 1) * 16 + 12;
+        }
+    }
+    // blur value number NBC*NBT: columns TX, TX+1 of every combination, one per lane (lanes 0 .. 2*NBC-1)
+    auto blur_extra_coords = [&](int bcj, int &c, int &xi, bool &ok, unsigned &q) {
+        c = llane >> 1;
+        xi = TX + (llane & 1);
+        const int rr = c >> 1;
+        const int y = phase + ((bcj + rr) << LOG2S) + ((c & 1) ? 1 : -1);
+        const int xs = x0 - 1 + xi;
+        ok = (llane < 2 * NBC) && y >= 0 && y < H && xs >= 0 && xs < W && (bcj + rr < b1);
+        q = (unsigned)min(max(y, 0), H - 1) * (unsigned)W + (unsigned)min(max(xs, 0), W - 1);
+    };
     // new rows of iteration j: lattice rows b0 + j*ROWS + 2 .. +ROWS-1 (+ROWS); its output rows start at b0 + j*ROWS
     auto loader_issue = [&](int j) {
         const int bcj = b0 + j * ROWS;
         if (bcj < b1) {
-            rows_load(lpx, bcj + 2, ROWS, llane, kLoaderGroup);
-            blur_load(lbv, bcj, llane, kLoaderGroup);
+            int rowq[ROWS], ldsrow[ROWS];
+#pragma unroll
+            for (int rr = 0; rr < ROWS; rr++) {     // wave-uniform
+                const int br = bcj + 2 + rr;
+                const int y = phase + (br << LOG2S);
+                rowq[rr] = min(y, H - 1) * W;
+                ldsrow[rr] = (slot_of(br) * RW * PXB) | (y < H ? 0 : (int)0x80000000);
+            }
+#pragma unroll
+            for (int m = 0; m < ML; m++) {
+                const bool r1 = (ROWS > 1) && l_r1[m];
+                const unsigned q = (unsigned)((r1 ? rowq[ROWS - 1] : rowq[0]) + l_xq[m]);                 // < 2^28
+                lpx[m].lds_off = (r1 ? ldsrow[ROWS - 1] : ldsrow[0]) + l_lds[m];    // bit 31: row, bit 30: column outside
+                lpx[m].cv = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(a.src) + q * 16u);
+                const float *n = reinterpret_cast<const float *>(reinterpret_cast<const char *>(a.nrm) + q * 12u);
+                const float *p = reinterpret_cast<const float *>(reinterpret_cast<const char *>(a.pos) + q * 12u);
+                lpx[m].nx = n[0]; lpx[m].ny = n[1]; lpx[m].nz = n[2];
+                lpx[m].px = p[0]; lpx[m].py = p[1]; lpx[m].pz = p[2];
+            }
+            if (a.blur_variance) {
+#pragma unroll
+                for (int c = 0; c < NBC; c++) {
+                    const int y = phase + ((bcj + (c >> 1)) << LOG2S) + ((c & 1) ? 1 : -1);              // wave-uniform
+                    const char *rowp = reinterpret_cast<const char *>(a.src) + (size_t)(min(max(y, 0), H - 1) * W) * 16u;
+#pragma unroll
+                    for (int t = 0; t < NBT; t++) lbv[c * NBT + t] = *reinterpret_cast<const float *>(rowp + b_voff[t]);
+                }
+                int c, xi; bool ok; unsigned q;
+                blur_extra_coords(bcj, c, xi, ok, q);
+                lbv[NBC * NBT] = a.src[q].w;
+            }
         }
     };
     auto loader_commit = [&](int j) {
         const int bcj = b0 + j * ROWS;
         if (bcj < b1) {
             rows_store(lpx);
-            if (a.blur_variance) blur_store(lbv, j & 1, llane, kLoaderGroup);
+            if (a.blur_variance) {
+                float *bp = blur + (j & 1) * (ROWS * 2 * BW) + llane;
+#pragma unroll
+                for (int c = 0; c < NBC; c++) {
+                    const int y = phase + ((bcj + (c >> 1)) << LOG2S) + ((c & 1) ? 1 : -1);
+                    const bool row_ok = y >= 0 && y < H && (bcj + (c >> 1) < b1);                      // wave-uniform
+#pragma unroll
+                    for (int t = 0; t < NBT; t++)
+                        bp[c * BW + t * kLoaderGroup] = (row_ok && b_ok[t]) ? lbv[c * NBT + t] : 0.0f;
+                }
+                int c, xi; bool ok; unsigned q;
+                blur_extra_coords(bcj, c, xi, ok, q);
+                if (llane < 2 * NBC) blur[(j & 1) * (ROWS * 2 * BW) + c * BW + xi] = ok ? lbv[NBC * NBT] : 0.0f;
+            }
         }
     };
 
@@ -284,7 +377,8 @@ __global__ __launch_bounds__(TX * ROWS + loader_threads(TX)) SVGF_STRIP_ATTR voi
         rows_store(px);
         if (a.blur_variance) blur_store(bv, 0, tid, NT);
     }
-    if (is_loader && lgroup >= 1) loader_issue(lgroup);     // iterations 1 .. kLoaderGroups-1: issue before the first barrier
+    if (kLoaderGroups == 1) { if (is_loader) loader_issue(1); }     // single group: commit, then re-issue, every iteration
+    else if (is_loader && lgroup >= 1) loader_issue(lgroup);        // iterations 1 .. kLoaderGroups-1: issue before the first barrier
     __syncthreads();
 
     int dbg_it = 0;
@@ -295,11 +389,12 @@ __global__ __launch_bounds__(TX * ROWS + loader_threads(TX)) SVGF_STRIP_ATTR voi
 
     if (is_loader) {
         // ================================ loader waves ================================
-        __builtin_amdgcn_s_setprio(3);
+        __builtin_amdgcn_s_setprio(SVGF_LOADER_PRIO);
         int it = 0;
         for (int bc = b0; bc < b1; bc += ROWS, it++, dbg_it++) {
             stamp(0);
-            if ((it + 1) % kLoaderGroups == lgroup) loader_commit(it + 1);          // issued kLoaderGroups-1 iterations ago
+            if (kLoaderGroups == 1) { loader_commit(it + 1); loader_issue(it + 2); }
+            else if ((it + 1) % kLoaderGroups == lgroup) loader_commit(it + 1);     // issued kLoaderGroups-1 iterations ago
             else if (it % kLoaderGroups == lgroup) loader_issue(it + kLoaderGroups);
             stamp(5);
             __syncthreads();
@@ -318,6 +413,9 @@ __global__ __launch_bounds__(TX * ROWS + loader_threads(TX)) SVGF_STRIP_ATTR voi
     int it = 0;
     for (int bc = b0; bc < b1; bc += ROWS, it++, dbg_it++) {
         stamp(0);
+#if SVGF_PROGRESS_PRIO
+        __builtin_amdgcn_s_setprio(3);
+#endif
         const int bo = bc + r;
         if (bo < b1 && x < W) {
             const int y = phase + (bo << LOG2S);
@@ -404,8 +502,12 @@ __global__ __launch_bounds__(TX * ROWS + loader_threads(TX)) SVGF_STRIP_ATTR voi
 #pragma unroll
                     for (int i = 0; i < 5; i++) {
                         if (i == 2 && j == 0) continue;
+#ifdef SVGF_HACK_NOSQRT
+                        dn[i] = s2[i].x; dx[i] = s2[i].y;
+#else
                         dn[i] = __builtin_amdgcn_sqrtf(s2[i].x);
                         dx[i] = __builtin_amdgcn_sqrtf(s2[i].y);
+#endif
                     }
                     __builtin_amdgcn_sched_barrier(0x100);
                     float e[5];
@@ -420,7 +522,11 @@ __global__ __launch_bounds__(TX * ROWS + loader_threads(TX)) SVGF_STRIP_ATTR voi
                     float w[5];
 #pragma unroll
                     for (int i = 0; i < 5; i++)
+#ifdef SVGF_HACK_NOEXP
+                        if (!(i == 2 && j == 0)) w[i] = -e[i];
+#else
                         if (!(i == 2 && j == 0)) w[i] = __builtin_amdgcn_exp2f(-e[i]);
+#endif
                     __builtin_amdgcn_sched_barrier(0x100);
 #pragma unroll
                     for (int i = 0; i < 5; i++) {
@@ -442,6 +548,20 @@ __global__ __launch_bounds__(TX * ROWS + loader_threads(TX)) SVGF_STRIP_ATTR voi
 #pragma unroll
                         for (int i = 0; i < 5; i++) { Ac[i] = An[i]; Bc[i] = Bn[i]; }
                     }
+                    // the wave that is ahead lowers its own priority, so the two compute waves of a SIMD finish together
+#if SVGF_PROGRESS_PRIO == 1
+                    if (j == -1) __builtin_amdgcn_s_setprio(2);
+                    if (j == 0) __builtin_amdgcn_s_setprio(1);
+                    if (j == 1) __builtin_amdgcn_s_setprio(0);
+#elif SVGF_PROGRESS_PRIO == 2
+                    if (j == -2) __builtin_amdgcn_s_setprio(2);
+                    if (j == -1) __builtin_amdgcn_s_setprio(1);
+                    if (j == 0) __builtin_amdgcn_s_setprio(0);
+#elif SVGF_PROGRESS_PRIO == 3
+                    if (j == -2) __builtin_amdgcn_s_setprio(2);
+                    if (j == 0) __builtin_amdgcn_s_setprio(1);
+                    if (j == 1) __builtin_amdgcn_s_setprio(0);
+#endif
                 }
             } else {
                 acc.rg = v2f{0.0f, 0.0f}; acc.bv = v2f{0.0f, 0.0f}; acc.ww = v2f{0.0f, 0.0f};
