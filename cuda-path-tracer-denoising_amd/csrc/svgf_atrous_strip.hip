@@ -381,10 +381,16 @@ __global__ __launch_bounds__(TX * ROWS + loader_threads(TX)) SVGF_STRIP_ATTR voi
     else if (is_loader && lgroup >= 1) loader_issue(lgroup);        // iterations 1 .. kLoaderGroups-1: issue before the first barrier
     __syncthreads();
 
+    // in-kernel timeline (tools, profiles/r01_strip_phase_timeline*.log): compiled in only with -DSVGF_STRIP_TIMELINE,
+    // because each stamp is a branch that splits the iteration into basic blocks the scheduler cannot move loads across
     int dbg_it = 0;
     auto stamp = [&](int phase_id) {
+#ifdef SVGF_STRIP_TIMELINE
         if (gm.dbg && bid == gm.dbg_block && (tid & 63) == 0 && dbg_it < 16)
             gm.dbg[((tid >> 6) * 16 + dbg_it) * 8 + phase_id] = __builtin_amdgcn_s_memtime();
+#else
+        (void)phase_id;
+#endif
     };
 
     if (is_loader) {
@@ -420,19 +426,21 @@ __global__ __launch_bounds__(TX * ROWS + loader_threads(TX)) SVGF_STRIP_ATTR voi
         if (bo < b1 && x < W) {
             const int y = phase + (bo << LOG2S);
             const char *rowc = colbase + (size_t)slot_of(bo) * RW * PXB + (size_t)(2 * S) * PXB;
+            // the centre pixel and its 3x3 variance neighbourhood are read in one basic block (one LDS round trip)
             const float4 A = *reinterpret_cast<const float4 *>(rowc);
             const float4 B = *reinterpret_cast<const float4 *>(rowc + 16);
             const float4 C = *reinterpret_cast<const float4 *>(rowc + 32);
             const bool careful = (*nan_seen != 0);
+            const float *bl = blur + (it & 1) * (ROWS * 2 * BW) + r * (2 * BW) + tx;    // column x-1 of row y-1
+            const float m0 = bl[0], m1 = bl[1], m2 = bl[2];
+            const float p0 = bl[BW], p1 = bl[BW + 1], p2 = bl[BW + 2];
+            const float c0v = *reinterpret_cast<const float *>(rowc - PXB + 44);
+            const float c2v = *reinterpret_cast<const float *>(rowc + PXB + 44);
 
-            // centre variance: 3x3 gaussian with out-of-image taps dropped and renormalised (:102-118)
-            float var = C.w;
-            if (a.blur_variance) {
-                const float *bl = blur + (it & 1) * (ROWS * 2 * BW) + r * (2 * BW) + tx;    // column x-1 of row y-1
-                const float m0 = bl[0], m1 = bl[1], m2 = bl[2];
-                const float p0 = bl[BW], p1 = bl[BW + 1], p2 = bl[BW + 2];
-                const float c0v = *reinterpret_cast<const float *>(rowc - PXB + 44);
-                const float c2v = *reinterpret_cast<const float *>(rowc + PXB + 44);
+            // centre variance: 3x3 gaussian with out-of-image taps dropped and renormalised (:102-118).  Evaluated
+            // unconditionally and selected (with blur_variance off the blur rows hold stale LDS, never used).
+            float var;
+            {
                 const float wr_m = (y - 1 >= 0) ? 0.25f : 0.0f, wr_p = (y + 1 < H) ? 0.25f : 0.0f;
                 const float wc_l = (x - 1 >= 0) ? 0.25f : 0.0f, wc_r = (x + 1 < W) ? 0.25f : 0.0f;
                 const float col_l = wr_m * m0 + 0.5f * c0v + wr_p * p0;
@@ -440,7 +448,8 @@ __global__ __launch_bounds__(TX * ROWS + loader_threads(TX)) SVGF_STRIP_ATTR voi
                 const float col_r = wr_m * m2 + 0.5f * c2v + wr_p * p2;
                 const float sum = wc_l * col_l + 0.5f * col_c + wc_r * col_r;
                 const float sumw = (wr_m + 0.5f + wr_p) * (wc_l + 0.5f + wc_r);
-                var = sum * __builtin_amdgcn_rcpf(sumw);
+                const float blurred = sum * __builtin_amdgcn_rcpf(sumw);
+                var = a.blur_variance ? blurred : C.w;
             }
             var = fmaxf(var, 0.0f);
 
