@@ -63,9 +63,12 @@ constexpr float kLog2e = 1.44269504088896340736f;
 #ifndef SVGF_LOADER_PRIO
 #define SVGF_LOADER_PRIO 2
 #endif
-constexpr int kLoaderGroups = SVGF_LOADER_GROUPS;               // groups take turns: issue / in flight / commit
-__host__ __device__ constexpr int loader_group(int tx) { return tx / SVGF_LOADER_DIV; }   // threads per loader group
-__host__ __device__ constexpr int loader_threads(int tx) { return kLoaderGroups * loader_group(tx); }
+// ROWS <= 2: SVGF_LOADER_GROUPS groups of TX / SVGF_LOADER_DIV threads take turns (issue / in flight / commit).
+// ROWS == 3: 12 compute waves leave room for 4 loader waves (1024 threads): one group of TX threads that commits and
+//            re-issues every iteration.
+__host__ __device__ constexpr int loader_groups(int rows) { return rows >= 3 ? 1 : SVGF_LOADER_GROUPS; }
+__host__ __device__ constexpr int loader_group(int tx, int rows) { return rows >= 3 ? tx : tx / SVGF_LOADER_DIV; }
+__host__ __device__ constexpr int loader_threads(int tx, int rows) { return loader_groups(rows) * loader_group(tx, rows); }
 
 struct StripGeom {
     int n_strips;   // strips of TX columns
@@ -148,15 +151,16 @@ __device__ __forceinline__ constexpr float neg_log2_binom(int i)
 // HASVAR = false: the level's filtered variance is not needed (last level, no colour-history copy): the two variance
 // accumulators (sum w^2, sum w^2 var) and the w*w product drop out of every tap.
 template <int LOG2S, int TX, int ROWS, bool HASVAR>
-__global__ __launch_bounds__(TX * ROWS + loader_threads(TX)) SVGF_STRIP_ATTR void k_atrous_strip(AtrousArgs a, StripGeom gm)
+__global__ __launch_bounds__(TX * ROWS + loader_threads(TX, ROWS)) SVGF_STRIP_ATTR void k_atrous_strip(AtrousArgs a, StripGeom gm)
 {
     constexpr int S = 1 << LOG2S;
     constexpr int RW = TX + 4 * S;          // staged pixels per lattice row
     constexpr int R = 4 + 2 * ROWS;         // ring slots: 4 + ROWS live, ROWS incoming
     constexpr int PXB = 48;                 // bytes per staged pixel
     constexpr int NC = TX * ROWS;           // compute threads
-    constexpr int kLoaderGroup = loader_group(TX);
-    constexpr int kLoaderThreads = loader_threads(TX);
+    constexpr int kLoaderGroups = loader_groups(ROWS);
+    constexpr int kLoaderGroup = loader_group(TX, ROWS);
+    constexpr int kLoaderThreads = loader_threads(TX, ROWS);
     constexpr int NT = NC + kLoaderThreads; // + the loader waves
     constexpr int BW = TX + 2;              // blur row: columns x0-1 .. x0+TX
     constexpr int RING_BYTES = R * RW * PXB;
@@ -185,7 +189,20 @@ __global__ __launch_bounds__(TX * ROWS + loader_threads(TX)) SVGF_STRIP_ATTR voi
 
     if (tid == 0) *nan_seen = 0;
 
-    auto slot_of = [&](int br) { return (br - (b0 - 2)) % R; };   // br >= b0-2 always
+    // ring slot of lattice row br (>= b0-2).  R is 8 for ROWS = 2 (a mask); for other R the iteration loops keep the
+    // slot of row bc-2 in `ring_base` (wave-uniform, advanced by ROWS per iteration) and wrap small offsets from it.
+    int ring_base = 0, ring_bc = b0;
+    auto slot_of = [&](int br) {
+        if constexpr ((R & (R - 1)) == 0) return (br - (b0 - 2)) & (R - 1);
+        else {
+            int s = ring_base + (br - (ring_bc - 2));      // offset in [0, 3*ROWS+2) < 2R
+            s -= (s >= R) ? R : 0;
+            s -= (s >= R) ? R : 0;
+            return s;
+        }
+    };
+    auto slot_mod = [&](int br) { return (br - (b0 - 2)) % R; };
+    auto ring_advance = [&]() { ring_bc += ROWS; ring_base += ROWS; ring_base -= (ring_base >= R) ? R : 0; };
 
     // ---- staging, split in two halves so that a batch of loads can stay in flight across a barrier ----
     // rows_load : global -> registers for lattice rows br_first .. br_first+nrows-1, pixels wi, wi+nw, ...
@@ -204,7 +221,7 @@ __global__ __launch_bounds__(TX * ROWS + loader_threads(TX)) SVGF_STRIP_ATTR voi
             const int y = phase + (br << LOG2S);
             const int xs = x0 - 2 * S + xi;
             const bool ok = (br >= 0) && (y < H) && (xs >= 0) && (xs < W);
-            px[m].lds_off = ((slot_of(br) * RW + xi) * PXB) | (ok ? 0 : (int)0x80000000);
+            px[m].lds_off = ((slot_mod(br) * RW + xi) * PXB) | (ok ? 0 : (int)0x80000000);
             const unsigned q = (unsigned)min(max(y, 0), H - 1) * (unsigned)W + (unsigned)min(max(xs, 0), W - 1);   // < 2^28
             // 32-bit byte offsets from the (wave-uniform) plane bases: global_load with SGPR base + VGPR offset
             px[m].cv = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(a.src) + q * 16u);
@@ -277,7 +294,7 @@ __global__ __launch_bounds__(TX * ROWS + loader_threads(TX)) SVGF_STRIP_ATTR voi
     // instruction count matters as much as their latency.
     int l_xq[ML];       // clamped source column
     int l_lds[ML];      // xi * PXB, bit 30 set if the column lies outside the image
-    bool l_r1[ML];      // pixel belongs to the second row of the iteration (ROWS == 2)
+    int l_rr[ML];       // which of the ROWS new rows the pixel belongs to
     int b_voff[NBT];    // byte offset of {clamped column}.w inside a source row
     bool b_ok[NBT];
     if (is_loader) {
@@ -288,7 +305,7 @@ __global__ __launch_bounds__(TX * ROWS + loader_threads(TX)) SVGF_STRIP_ATTR voi
             const int xs = x0 - 2 * S + xi;
             l_xq[m] = min(max(xs, 0), W - 1);
             l_lds[m] = (xi * PXB) | ((xs >= 0 && xs < W) ? 0 : 0x40000000);
-            l_r1[m] = (rr != 0);
+            l_rr[m] = rr;
         }
 #pragma unroll
         for (int t = 0; t < NBT; t++) {
@@ -321,9 +338,11 @@ __global__ __launch_bounds__(TX * ROWS + loader_threads(TX)) SVGF_STRIP_ATTR voi
             }
 #pragma unroll
             for (int m = 0; m < ML; m++) {
-                const bool r1 = (ROWS > 1) && l_r1[m];
-                const unsigned q = (unsigned)((r1 ? rowq[ROWS - 1] : rowq[0]) + l_xq[m]);                 // < 2^28
-                lpx[m].lds_off = (r1 ? ldsrow[ROWS - 1] : ldsrow[0]) + l_lds[m];    // bit 31: row, bit 30: column outside
+                int rq = rowq[0], lr = ldsrow[0];
+#pragma unroll
+                for (int rr = 1; rr < ROWS; rr++) { rq = (l_rr[m] == rr) ? rowq[rr] : rq; lr = (l_rr[m] == rr) ? ldsrow[rr] : lr; }
+                const unsigned q = (unsigned)(rq + l_xq[m]);                         // < 2^28
+                lpx[m].lds_off = lr + l_lds[m];                                      // bit 31: row, bit 30: column outside
                 lpx[m].cv = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(a.src) + q * 16u);
                 const float *n = reinterpret_cast<const float *>(reinterpret_cast<const char *>(a.nrm) + q * 12u);
                 const float *p = reinterpret_cast<const float *>(reinterpret_cast<const char *>(a.pos) + q * 12u);
@@ -405,6 +424,7 @@ __global__ __launch_bounds__(TX * ROWS + loader_threads(TX)) SVGF_STRIP_ATTR voi
             stamp(5);
             __syncthreads();
             stamp(6);
+            ring_advance();
         }
         return;
     }
@@ -603,6 +623,7 @@ __global__ __launch_bounds__(TX * ROWS + loader_threads(TX)) SVGF_STRIP_ATTR voi
         stamp(5);
         __syncthreads();
         stamp(6);
+        ring_advance();
     }
 }
 
@@ -631,20 +652,22 @@ hipError_t launch_cfg(const AtrousArgs &a, hipStream_t s)
         if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) n_cu = 256;
     }
     int bpc = (int)((160 * 1024) / lds);
-    constexpr int kLoaderThreads = loader_threads(TX);
+    constexpr int kLoaderThreads = loader_threads(TX, ROWS);
     if (bpc > 2048 / (TX * ROWS + kLoaderThreads)) bpc = 2048 / (TX * ROWS + kLoaderThreads);
     if (bpc < 1) bpc = 1;
     const int capacity = n_cu * bpc;
-    int best_L = ((nb_max + ROWS - 1) / ROWS) * ROWS;
+    int best_L = nb_max;
     long best_cost = -1;
-    for (int L = ROWS * 4; L <= nb_max + ROWS; L += ROWS) {
+    for (int L = ROWS * 4; L <= nb_max + ROWS; L++) {        // L need not be a multiple of ROWS: the last iteration idles rows
         const int segs_l = (nb_max + L - 1) / L;
-        const long blocks = (long)gm.n_strips * S * segs_l;
-        const long rounds = (blocks + capacity - 1) / capacity;
-        const long cost = rounds * (L + 8);
+        // (phase, segment) groups are dealt round-robin to the 8 XCDs (blockIdx % 8), all strips of a group to the same
+        // XCD: the busiest XCD, with ceil(groups / 8) groups, sets the number of rounds
+        const long blocks_xcd = (long)gm.n_strips * ((S * segs_l + 7) / 8);
+        const long rounds = (blocks_xcd + capacity / 8 - 1) / (capacity / 8);
+        const long cost = rounds * ((L + ROWS - 1) / ROWS * ROWS + 8);
         if (best_cost < 0 || cost <= best_cost) { best_cost = cost; best_L = L; }   // ties: fewer, longer workgroups
     }
-    if (const char *e = getenv("SVGF_STRIP_SEGROWS")) { int v = atoi(e); if (v > 0) best_L = ((v + ROWS - 1) / ROWS) * ROWS; }
+    if (const char *e = getenv("SVGF_STRIP_SEGROWS")) { int v = atoi(e); if (v > 0) best_L = v; }
     gm.seg_rows = best_L;
     gm.n_segs = (nb_max + best_L - 1) / best_L;
     gm.n_groups = S * gm.n_segs;
@@ -666,7 +689,9 @@ hipError_t launch_cfg(const AtrousArgs &a, hipStream_t s)
         (void)hipStreamSynchronize(s);
         unsigned long long h[16 * 16 * 8];
         (void)hipMemcpy(h, dbg_buf, sizeof(h), hipMemcpyDeviceToHost);
-        if (prints++ < 10) {
+        static int skip = getenv("SVGF_STRIP_DBG_SKIP") ? atoi(getenv("SVGF_STRIP_DBG_SKIP")) : 0;    // warm launches only
+        if (skip > 0) skip--;
+        else if (prints++ < 10) {
             const int nw = (TX * ROWS + kLoaderThreads) / 64;
             fprintf(stderr, "[strip dbg] S=%d TX=%d ROWS=%d blocks=%d segs=%d seg_rows=%d lds=%zu waves=%d (last 6 = loaders)\n", S, TX,
                     ROWS, nblocks, gm.n_segs, gm.seg_rows, lds, nw);
@@ -689,13 +714,18 @@ hipError_t launch_cfg(const AtrousArgs &a, hipStream_t s)
 }
 
 // default configuration per dilation; SVGF_STRIP_TX / SVGF_STRIP_ROWS override for tuning runs
-void pick(int log2s, int &tx, int &rows)
+void pick(int log2s, int W, int &tx, int &rows)
 {
-    static const int def_tx[6] = { 0, 256, 256, 256, 256, 256 };
-    static const int def_rows[6] = { 0, 2, 2, 2, 2, 2 };
-    tx = def_tx[log2s]; rows = def_rows[log2s];
+    // 256 columns x 2 rows per workgroup everywhere (profiles/r01_exp_tx_rows.log):
+    //  * 128-column strips (two workgroups per CU) run a lone S <= 8 level 3-4 % faster at 1080p (equal at 3840), but
+    //    the whole frame gets slower (6.46 vs 6.94 Gpix/s) once the next frame's temporal pass shares the GPU with
+    //    levels 2-3; at S >= 16 the 4S halo columns make narrow strips lose outright;
+    //  * ROWS = 3 (12 compute waves) is correct but not faster: two compute waves already saturate a SIMD's VALU.
+    (void)W;
+    tx = 256; rows = 2;
     if (const char *e = getenv("SVGF_STRIP_TX")) { int v = atoi(e); if (v == 128 || v == 256) tx = v; }
-    if (const char *e = getenv("SVGF_STRIP_ROWS")) { int v = atoi(e); if (v == 1 || v == 2) rows = v; }
+    if (const char *e = getenv("SVGF_STRIP_ROWS")) { int v = atoi(e); if (v >= 1 && v <= 3) rows = v; }
+    if (rows == 3 && tx != 256) rows = 2;
     // LDS budget: ring + blur rows <= 160 KiB
     const int S = 1 << log2s;
     while ((size_t)(4 + 2 * rows) * (tx + 4 * S) * 48 + (size_t)2 * rows * 2 * (tx + 2) * 4 + 16 > 160 * 1024 && rows > 1) rows--;
@@ -717,7 +747,8 @@ hipError_t launch_atrous_strip(const AtrousArgs &a, hipStream_t s)
     int log2s = 0;
     while ((1 << log2s) < a.step) log2s++;
     int tx, rows;
-    pick(log2s, tx, rows);
+    pick(log2s, a.W, tx, rows);
+    STRIP_CASE(1, 256, 3) STRIP_CASE(2, 256, 3) STRIP_CASE(3, 256, 3)
     STRIP_CASE(1, 128, 1) STRIP_CASE(1, 128, 2) STRIP_CASE(1, 256, 1) STRIP_CASE(1, 256, 2)
     STRIP_CASE(2, 128, 1) STRIP_CASE(2, 128, 2) STRIP_CASE(2, 256, 1) STRIP_CASE(2, 256, 2)
     STRIP_CASE(3, 128, 1) STRIP_CASE(3, 128, 2) STRIP_CASE(3, 256, 1) STRIP_CASE(3, 256, 2)
