@@ -176,7 +176,9 @@ def main():
                          "note": "timed-region launches include levels that run beside the next frame's temporal pass "
                                  "(cross-frame overlap); 'isolated' is the same kernel with the GPU to itself",
                          "isolated": {"mean_launch_us": round(iso_us, 2), "achieved": round(iso_gbs, 1),
-                                      "frac": round(iso_gbs / HBM_PEAK_GBS, 4), "launches_timed": len(iso_atrous_ms)}},
+                                      "frac": round(iso_gbs / HBM_PEAK_GBS, 4), "launches_timed": len(iso_atrous_ms)},
+                         # the secondary limiter.  24 taps x (2 v_sqrt + 1 v_exp) + 5 (centre, normalisation) per pixel-level
+                         "transcendental_gops_isolated": round(77 * W * H / (iso_us * 1e-6) / 1e9, 1)},
             "kernels_us": {"temporal": round(float(np.mean(temporal_ms)) * 1e3, 2), "atrous_level_mean": round(a_ms * 1e3, 2)},
             "frame_algorithmic_gbs": round(FRAME_BYTES_PER_PIXEL * W * H / (dt / a.steps) / 1e9 / world * 1.0, 1),
         }

@@ -19,16 +19,15 @@
 //     blur rows (as in the strip kernel)
 // = 151 KB at S = 8; S = 16, 32 do not fit and stay on the strip kernel.
 //
-// Work-group = 512 compute threads + 3 loader groups of 128 (as in the strip kernel).  T entries of the 2S halo columns
+// Work-group = 512 compute threads + 2 loader groups of 128 (as in the strip kernel).  T entries of the 2S halo columns
 // on either side (needed by the outermost output columns) are computed by the loader group about to issue its loads in
 // that iteration; the forward terms of the two halo rows above a segment are computed once in the prologue.
 // Two barriers per iteration: T published -> pass C;  pass C done / new rows committed -> next pass G.
 //
 // STATUS (round 1): EXPERIMENTAL, opt-in (SvgfParams::kernel_variant = 3).  Results are correct (tests/test_parity_gpu.py
-// runs it against the reference goldens), but hipcc needs ~175 VGPRs for this body while 14 waves per CU leave 128, so it
-// spills to scratch and runs 160-175 us per 1080p level against 60 us for the strip kernel
-// (profiles/r01_share_kernel_experiment.log).  Getting the predicted 0.7x needs a hand-scheduled register allocation
-// (or splitting pass G / pass C into separately compiled wave roles); left for a later round.
+// runs it against the reference goldens).  With two loader groups (12 waves, 168 VGPRs: no spilling) and the six-stage
+// software pipeline below it runs 66-71 us per 1080p level against 55 us for the strip kernel: the second barrier per
+// iteration cuts the work into short phases in which the waves of a SIMD stall together.
 #include "svgf_kernels.h"
 
 #include <cstdio>
