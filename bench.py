@@ -63,9 +63,12 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--config", default="1080p-static", choices=["1080p-static", "1080p-moving", "4k-static"],
+    ap.add_argument("--config", default="1080p-static", choices=["1080p-static", "1080p-moving", "4k-static", "4k-moving"],
                     help="1080p-static = BASELINE configs[1] (the default, the headline metric); 1080p-moving = configs[2] "
-                         "(64-frame moving-camera sequence); 4k-static = configs[3]")
+                         "(64-frame moving-camera sequence); 4k-static = configs[3]; 4k-moving = the same at 3840x2160")
+    ap.add_argument("--host-inputs", action="store_true",
+                    help="render the synthetic frames with numpy and upload them (default: the device-side producer, "
+                         "svgf_synth_render, SURVEY.md 8f row f1; both give the same frames bit for bit)")
     a = ap.parse_args()
 
     import torch
@@ -86,9 +89,9 @@ def main():
     dev = torch.device("cuda", local_rank)
 
     global W, H
-    if a.config == "4k-static":
+    if a.config.startswith("4k"):
         W, H = 3840, 2160
-    moving = (a.config == "1080p-moving")
+    moving = a.config.endswith("moving")
     # one rank per node builds (normally a no-op: the libraries are prebuilt in-tree); the others wait
     if local_rank == 0:
         ge.build()
@@ -101,10 +104,20 @@ def main():
     # every rank owns one independent sequence (its own seed); 4 distinct noisy frames, static camera, resident in HBM
     seq = pkg.farm.shard(world, world, rank)[0]
     nsrc = 64 if moving else 4
-    frames = [pkg.synth.render_frame(W, H, f, seed=1000 + seq, moving=moving) for f in range(nsrc)]
-    d_in = [torch.from_numpy(f[0]).to(dev) for f in frames]
-    d_g = [torch.from_numpy(f[1].view(np.uint8).reshape(-1)).to(dev) for f in frames]
-    cams = [pkg.SvgfCamera.from_dict(f[2]) for f in frames]
+    if a.host_inputs:
+        frames = [pkg.synth.render_frame(W, H, f, seed=1000 + seq, moving=moving, noise_model="hash") for f in range(nsrc)]
+        d_in = [torch.from_numpy(f[0]).to(dev) for f in frames]
+        d_g = [torch.from_numpy(f[1].view(np.uint8).reshape(-1)).to(dev) for f in frames]
+        cam_dicts = [f[2] for f in frames]
+    else:   # produced where the reference produces them: on the device (the path tracer's role)
+        cam_dicts = [pkg.synth.camera_for_frame(f, moving) for f in range(nsrc)]
+        d_in = [torch.empty((H, W, 3), dtype=torch.float32, device=dev) for _ in range(nsrc)]
+        d_g = [torch.empty((H * W * 52,), dtype=torch.uint8, device=dev) for _ in range(nsrc)]
+        for f in range(nsrc):
+            pkg.binding.synth_render(d_in[f], d_g[f], W, H, cam_dicts[f], f, seed=1000 + seq, device=local_rank)
+        torch.cuda.synchronize(dev)
+        frames = None
+    cams = [pkg.SvgfCamera.from_dict(c) for c in cam_dicts]
     out = torch.empty((H, W, 3), dtype=torch.float32, device=dev)
     den = pkg.Denoiser(W, H, device=local_rank)
     stream = torch.cuda.current_stream(dev)
@@ -160,7 +173,7 @@ def main():
         iso_us = float(np.mean(iso_atrous_ms)) * 1e3
         iso_gbs = ATROUS_BYTES_PER_PIXEL * W * H / (iso_us * 1e-6) / 1e9
         line = {
-            "metric": "SVGF Mpixels/s (full pipeline) at 1080p; a-trous HBM GB/s vs roofline" if a.config != "4k-static" else "SVGF Mpixels/s (full pipeline) at 4K; a-trous HBM GB/s vs roofline",
+            "metric": "SVGF Mpixels/s (full pipeline) at 1080p; a-trous HBM GB/s vs roofline" if not a.config.startswith("4k") else "SVGF Mpixels/s (full pipeline) at 4K; a-trous HBM GB/s vs roofline",
             "value": round(value, 2), "unit": "Mpixels/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(dt / a.steps * 1e3, 5), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -185,6 +198,9 @@ def main():
         if a.config != "1080p-static":
             line["roofline"]["traffic"] = None      # the committed PMC passes are for the 1080p-static workload
         if world == 1 and not a.no_cpu_baseline and a.config == "1080p-static":
+            if frames is None:   # bring the device-produced frames to the host for the CPU leg
+                frames = [(d_in[f].cpu().numpy(), d_g[f].cpu().numpy().view(pkg.synth.GBUFFER_DTYPE).reshape(H, W), cam_dicts[f])
+                          for f in range(min(nsrc, 4))]
             host_frames = [(f[0], f[1], f[2]) for f in frames]
             line["cpu_baseline"] = cpu_baseline(pkg, host_frames, params)
         print(json.dumps(line), flush=True)

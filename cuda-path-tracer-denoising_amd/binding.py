@@ -27,7 +27,8 @@ MAX_LEVELS = 10
 # every symbol include/svgf.h declares
 EXPORTS = ["svgf_version", "svgf_params_default", "svgf_create", "svgf_destroy", "svgf_reset", "svgf_denoise",
            "svgf_denoise_host", "svgf_sync", "svgf_last_error", "svgf_width", "svgf_height", "svgf_read_state",
-           "svgf_set_capture", "svgf_profile_enable", "svgf_profile_stride", "svgf_profile_frames", "svgf_profile_read"]
+           "svgf_set_capture", "svgf_profile_enable", "svgf_profile_stride", "svgf_profile_frames", "svgf_profile_read",
+           "svgf_synth_camera", "svgf_synth_render"]
 
 
 class SvgfCamera(C.Structure):
@@ -56,6 +57,11 @@ class SvgfParams(C.Structure):
                 raise AttributeError(k)
             setattr(self, k, v)
         return self
+
+
+class SvgfSynthParams(C.Structure):
+    _fields_ = [("frame", C.c_int), ("seed", C.c_int), ("noise", C.c_float), ("fireflies", C.c_float),
+                ("pixel_length", C.c_float * 2)]
 
 
 def reference_defaults() -> SvgfParams:
@@ -112,6 +118,8 @@ def load_library(path: str | None = None):
     lib.svgf_profile_frames.argtypes = [vp]
     lib.svgf_profile_frames.restype = C.c_longlong
     lib.svgf_profile_read.argtypes = [vp, ip, ip, C.POINTER(ip), C.POINTER(C.c_float), C.POINTER(ip)]
+    lib.svgf_synth_camera.argtypes = [ip, ip, ip, ip, C.POINTER(SvgfCamera), C.POINTER(C.c_float)]
+    lib.svgf_synth_render.argtypes = [ip, vp, vp, ip, ip, C.POINTER(SvgfCamera), C.POINTER(SvgfSynthParams), vp]
     if path == LIB_PATH:
         _lib = lib
     return lib
@@ -219,3 +227,35 @@ class Denoiser:
         n = C.c_int()
         self._check(self.lib.svgf_profile_read(self.h, slot, 32, kinds, ms, C.byref(n)), "svgf_profile_read")
         return [(kinds[i], ms[i]) for i in range(n.value)]
+
+
+# --- the denoiser's inputs produced on the device -------------------------------------------
+def synth_camera(frame: int, moving: bool, width: int, height: int):
+    """svgf_synth_camera: (SvgfCamera, (plx, ply)) computed by the library (C float math)."""
+    lib = load_library()
+    cam = SvgfCamera()
+    pl = (C.c_float * 2)()
+    rc = lib.svgf_synth_camera(int(frame), int(bool(moving)), int(width), int(height), C.byref(cam), pl)
+    if rc != SVGF_OK:
+        raise SvgfError(f"svgf_synth_camera failed ({rc})")
+    return cam, (pl[0], pl[1])
+
+
+def synth_render(out_rgb, out_gbuffer, width: int, height: int, camera, frame: int, seed: int = 1,
+                 noise: float = 0.6, fireflies: float = 0.02, pixel_length=None, device: int = 0, stream=None):
+    """svgf_synth_render: writes packed rgb (H*W*3 float32) and 52-byte texels (H*W*52 bytes) into device memory
+    (torch CUDA tensors or raw pointers).  `camera` is an SvgfCamera or a synth.camera_for_frame() dict;
+    `pixel_length` defaults to synth._pixel_length(width, height, 45) so that host and device producers agree."""
+    lib = load_library()
+    cam = camera if isinstance(camera, SvgfCamera) else SvgfCamera.from_dict(camera)
+    if pixel_length is None:
+        from . import synth as _synth
+        pixel_length = _synth._pixel_length(width, height, 45.0)
+    sp = SvgfSynthParams(int(frame), int(seed), float(noise), float(fireflies))
+    sp.pixel_length[0] = float(pixel_length[0])
+    sp.pixel_length[1] = float(pixel_length[1])
+    s = None if stream is None else (stream if isinstance(stream, int) else stream.cuda_stream)
+    rc = lib.svgf_synth_render(int(device), _ptr(out_rgb), _ptr(out_gbuffer), int(width), int(height), C.byref(cam),
+                               C.byref(sp), s)
+    if rc != SVGF_OK:
+        raise SvgfError(f"svgf_synth_render failed ({rc})")

@@ -62,9 +62,34 @@ _ALBEDO = {0: (0.85, 0.85, 0.85), 1: (0.85, 0.85, 0.85), 2: (0.85, 0.85, 0.85), 
 _LIGHT = np.array([0.0, 9.5, 0.0], F)
 
 
+def hash_uniform(seed: int, frame: int, n: int, k: int):
+    """Counter-based uniform float32 in [0,1) per pixel index 0..n-1 and stream k: a 32-bit integer mix of
+    (seed, frame, pixel, k), top 24 bits scaled by 2^-24.  Plain uint32 arithmetic, so the device-side producer
+    (csrc/svgf_synth.hip: synth_hash) reproduces it bit for bit."""
+    with np.errstate(over="ignore"):
+        x = (np.arange(n, dtype=np.uint32) * np.uint32(0x9E3779B1) + np.uint32((k * 0x85EBCA77) & 0xFFFFFFFF)
+             + np.uint32((frame * 0xC2B2AE3D) & 0xFFFFFFFF) + np.uint32((seed * 0x27D4EB2F) & 0xFFFFFFFF))
+        x ^= x >> np.uint32(15)
+        x *= np.uint32(0x2C1B3C6D)
+        x ^= x >> np.uint32(12)
+        x *= np.uint32(0x297A2D39)
+        x ^= x >> np.uint32(15)
+    return ((x >> np.uint32(8)).astype(np.float32) * F(1.0 / 16777216.0)).astype(F)
+
+
+def scene_constants():
+    """The analytic scene as flat float32 arrays, in the layout csrc/svgf_synth.hip takes (SvgfSynthScene)."""
+    sph = []
+    for c, r, g in _SPHERES:
+        sph.append(dict(c=c, r=r, gid=g))
+    return dict(spheres=sph, box_min=_BOX[0], box_max=_BOX[1], box_gid=_BOX[2], light=_LIGHT, albedo=_ALBEDO)
+
+
 def render_frame(W: int, H: int, frame: int, seed: int = 1, moving: bool = False, noise: float = 0.6,
-                 fireflies: float = 0.02, cam: dict | None = None):
-    """Returns (color float32[H,W,3], gbuffer GBUFFER_DTYPE[H,W], camera dict)."""
+                 fireflies: float = 0.02, cam: dict | None = None, noise_model: str = "pcg64"):
+    """Returns (color float32[H,W,3], gbuffer GBUFFER_DTYPE[H,W], camera dict).
+    noise_model "pcg64": numpy's default generator (the model the committed goldens were made with);
+                "hash" : hash_uniform(), the model the device-side producer implements (tests/test_synth_device_gpu.py)."""
     if cam is None:
         cam = camera_for_frame(frame, moving)
     plx, ply = _pixel_length(W, H, cam["fovy_deg"])
@@ -99,7 +124,7 @@ def render_frame(W: int, H: int, frame: int, seed: int = 1, moving: bool = False
         for c, r, g in _SPHERES:
             oc = o - c
             b = np.sum(d * oc[None, None, :], axis=-1, dtype=F)
-            cc = F(np.dot(oc, oc)) - r * r
+            cc = F(F(oc[0] * oc[0] + oc[1] * oc[1]) + oc[2] * oc[2]) - r * r      # fixed order (the device producer mirrors it)
             disc = b * b - cc
             t = np.where(disc > 0, -b - np.sqrt(np.maximum(disc, 0)), np.inf).astype(F)
             ph = o[None, None, :] + t[..., None] * d
@@ -134,12 +159,20 @@ def render_frame(W: int, H: int, frame: int, seed: int = 1, moving: bool = False
     lam = np.maximum(np.sum(ldir * nrm, axis=-1, dtype=F), F(0))
     shade = (F(0.15) + F(30.0) * lam / (F(4.0) + dist2)).astype(F)
 
-    rng = np.random.default_rng([int(seed), int(frame), W, H])
-    u = rng.random((H, W), dtype=np.float32)
-    v = rng.random((H, W), dtype=np.float32)
+    if noise_model == "hash":
+        u = hash_uniform(seed, frame, W * H, 0).reshape(H, W)
+        v = hash_uniform(seed, frame, W * H, 1).reshape(H, W)
+        rc = np.stack([hash_uniform(seed, frame, W * H, 2 + c).reshape(H, W) for c in range(3)], axis=-1)
+    elif noise_model == "pcg64":
+        rng = np.random.default_rng([int(seed), int(frame), W, H])
+        u = rng.random((H, W), dtype=np.float32)
+        v = rng.random((H, W), dtype=np.float32)
+        rc = rng.random((H, W, 3), dtype=np.float32)
+    else:
+        raise ValueError(noise_model)
     mult = (F(1.0) + F(noise) * (F(2.0) * u - F(1.0))).astype(F)
     mult = np.where(v < F(fireflies), mult * F(6.0), mult).astype(F)
-    chroma = (F(1.0) + F(0.1 * noise) * (rng.random((H, W, 3), dtype=np.float32) - F(0.5))).astype(F)
+    chroma = (F(1.0) + F(F(0.1) * F(noise)) * (rc - F(0.5))).astype(F)      # amplitude as an fp32 product (device mirrors it)
     color = (alb * shade[..., None] * mult[..., None] * chroma).astype(F)
     color = np.where(miss[..., None], F(0), color).astype(F)
 

@@ -158,6 +158,25 @@ int svgf_profile_stride(svgf_ctx *ctx, int every_kth_frame);
 long long svgf_profile_frames(const svgf_ctx *ctx);
 int svgf_profile_read(svgf_ctx *ctx, int slot, int max_entries, int *kinds, float *ms, int *n_out);
 
+/* ---- "next" row f1: device-side producer of the denoiser's inputs ---------------------------------
+ * In the reference the 1-spp colour and the G-buffer are produced on the device by the path tracer (primary rays
+ * src/pathtrace.cu:187-208, first-hit G-buffer fill src/pathtrace.cu:317-323) and handed to denoise() as device
+ * pointers (src/pathtrace.cu:436-438).  These two entry points stand in for that producer with the analytic
+ * Cornell-like scene of SURVEY.md 8(d): svgf_synth_camera replaces runCuda()'s camera update (src/main.cpp:154-190,
+ * pixelLength of src/scene.cpp:159-166), svgf_synth_render replaces generateRayFromCamera + the first-bounce G-buffer
+ * write + the 1-spp radiance.  Stateless; outputs are packed rgb (12 B/px) and SvgfGBufferTexel (52 B/px) in device
+ * memory, ready for svgf_denoise on the same stream. */
+typedef struct SvgfSynthParams {
+    int   frame;             /* frame index: noise stream, and camera phase when the camera moves */
+    int   seed;              /* sequence seed */
+    float noise;             /* multiplicative noise amplitude (0.6) */
+    float fireflies;         /* fraction of pixels 6x brighter (0.02) */
+    float pixel_length[2];   /* Camera::pixelLength, as svgf_synth_camera returns it */
+} SvgfSynthParams;
+int svgf_synth_camera(int frame, int moving, int width, int height, SvgfCamera *cam, float pixel_length[2]);
+int svgf_synth_render(int device, void *out_rgb_dev, void *out_gbuffer_dev, int width, int height,
+                      const SvgfCamera *cam, const SvgfSynthParams *sp, void *stream);
+
 #ifdef __cplusplus
 }
 #endif
