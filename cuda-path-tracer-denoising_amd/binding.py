@@ -28,7 +28,7 @@ MAX_LEVELS = 10
 EXPORTS = ["svgf_version", "svgf_params_default", "svgf_create", "svgf_destroy", "svgf_reset", "svgf_denoise",
            "svgf_denoise_host", "svgf_sync", "svgf_last_error", "svgf_width", "svgf_height", "svgf_read_state",
            "svgf_set_capture", "svgf_profile_enable", "svgf_profile_stride", "svgf_profile_frames", "svgf_profile_read",
-           "svgf_synth_camera", "svgf_synth_render"]
+           "svgf_synth_camera", "svgf_synth_render", "svgf_display_pack", "svgf_save_png"]
 
 
 class SvgfCamera(C.Structure):
@@ -120,6 +120,8 @@ def load_library(path: str | None = None):
     lib.svgf_profile_read.argtypes = [vp, ip, ip, C.POINTER(ip), C.POINTER(C.c_float), C.POINTER(ip)]
     lib.svgf_synth_camera.argtypes = [ip, ip, ip, ip, C.POINTER(SvgfCamera), C.POINTER(C.c_float)]
     lib.svgf_synth_render.argtypes = [ip, vp, vp, ip, ip, C.POINTER(SvgfCamera), C.POINTER(SvgfSynthParams), vp]
+    lib.svgf_display_pack.argtypes = [ip, vp, vp, vp, ip, ip, vp]
+    lib.svgf_save_png.argtypes = [C.c_char_p, vp, ip, ip, ip]
     if path == LIB_PATH:
         _lib = lib
     return lib
@@ -259,3 +261,23 @@ def synth_render(out_rgb, out_gbuffer, width: int, height: int, camera, frame: i
                                C.byref(sp), s)
     if rc != SVGF_OK:
         raise SvgfError(f"svgf_synth_render failed ({rc})")
+
+
+# --- the step after denoise() ----------------------------------------------------------------
+def display_pack(pbo, left, right, width: int, height: int, device: int = 0, stream=None):
+    """svgf_display_pack: `left` | `right` (packed rgb float, device) -> (height, 2*width, 4) uint8 in device memory."""
+    lib = load_library()
+    s = None if stream is None else (stream if isinstance(stream, int) else stream.cuda_stream)
+    rc = lib.svgf_display_pack(int(device), _ptr(pbo), _ptr(left), _ptr(right), int(width), int(height), s)
+    if rc != SVGF_OK:
+        raise SvgfError(f"svgf_display_pack failed ({rc})")
+
+
+def save_png(path: str, rgb: np.ndarray, mirror_x: bool = True):
+    """svgf_save_png: host float32 (H, W, 3) -> 8-bit RGB PNG, with the reference's x mirror by default."""
+    lib = load_library()
+    rgb = np.ascontiguousarray(rgb, dtype=np.float32)
+    h, w = rgb.shape[0], rgb.shape[1]
+    rc = lib.svgf_save_png(os.fsencode(path), rgb.ctypes.data, int(w), int(h), int(bool(mirror_x)))
+    if rc != SVGF_OK:
+        raise SvgfError(f"svgf_save_png failed ({rc})")

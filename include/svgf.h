@@ -177,6 +177,16 @@ int svgf_synth_camera(int frame, int moving, int width, int height, SvgfCamera *
 int svgf_synth_render(int device, void *out_rgb_dev, void *out_gbuffer_dev, int width, int height,
                       const SvgfCamera *cam, const SvgfSynthParams *sp, void *stream);
 
+/* ---- "next" row f2: the step right after denoise() ------------------------------------------------
+ * svgf_display_pack: reference sendTwoImagesToPBO (src/pathtrace.cu:45-77, launched at :446): `left` (the 1-spp
+ *   image) and `right` (the denoised image), both packed rgb floats in device memory, side by side into a
+ *   (2*width) x height RGBA8 buffer in device memory; channel = clamp((int)(v * 255.0), 0, 255), alpha 0.
+ * svgf_save_png: reference saveImage + image::savePNG (src/main.cpp:131-152, src/image.cpp:22-39) for a HOST image:
+ *   clamp(v, 0, 1) * 255.f truncated to a byte, 8-bit RGB PNG; mirror_x != 0 flips the image in x as saveImage does. */
+int svgf_display_pack(int device, void *pbo_rgba8_dev, const void *left_rgb_dev, const void *right_rgb_dev, int width,
+                      int height, void *stream);
+int svgf_save_png(const char *path, const float *rgb_host, int width, int height, int mirror_x);
+
 #ifdef __cplusplus
 }
 #endif
