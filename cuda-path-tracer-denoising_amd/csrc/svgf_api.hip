@@ -389,6 +389,7 @@ extern "C" int svgf_denoise(svgf_ctx *c, void *out_rgb_dev, const void *in_rgb_d
             t.nrm_cur = c->nrm[gnew]; t.gid_cur = c->gid[gnew]; t.pos_cur = c->pos[gnew];
             memcpy(t.M, c->view_prev, sizeof(t.M));
             t.W = c->W; t.H = c->H; t.color_alpha_min = p->color_alpha; t.moment_alpha_min = p->moment_alpha;
+            t.reproj_sx = p->reproj_scale[0]; t.reproj_sy = p->reproj_scale[1];
             LAUNCH_T(SVGF_KERNEL_TEMPORAL, launch_temporal(t, ts, overlap && c->ev_hist_valid));
         } else {
             LAUNCH_T(SVGF_KERNEL_PREPARE, launch_prepare(in, g, c->cv[acc], c->nrm[gnew], c->gid[gnew], c->pos[gnew], c->W, c->H, ts));

@@ -38,6 +38,7 @@ struct TemporalArgs {
     float M[16];              // previous view matrix, column-major
     int W, H;
     float color_alpha_min, moment_alpha_min;
+    float reproj_sx, reproj_sy;   // SvgfParams::reproj_scale; 0 = reference mapping
 };
 
 hipError_t launch_temporal(const TemporalArgs &a, hipStream_t s, bool single_wave_blocks);

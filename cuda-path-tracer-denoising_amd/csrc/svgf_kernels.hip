@@ -81,6 +81,8 @@ __global__ __launch_bounds__(BLOCK) void k_temporal(TemporalArgs a)
             vs[r] = a0 + a1;
         }
         float clipx = vs[0] / vs[2], clipy = vs[1] / vs[2];          // no tan(fov), no aspect (:202-203)
+        if (a.reproj_sx > 0.0f) clipx = clipx / a.reproj_sx;          // f4 extension: exact for any fov / aspect
+        if (a.reproj_sy > 0.0f) clipy = clipy / a.reproj_sy;
         float ndcx = -clipx * 0.5f + 0.5f, ndcy = -clipy * 0.5f + 0.5f;
         float prevx = ndcx * (float)a.W - 0.5f, prevy = ndcy * (float)a.H - 0.5f;
         float fx = floorf(prevx), fy = floorf(prevy);

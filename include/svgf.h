@@ -81,7 +81,12 @@ typedef struct SvgfParams {
     int   inputs_ready;       /* 1: in_rgb/gbuffer are complete when svgf_denoise is CALLED (no producer still pending on
                                  `stream`).  Lets the temporal pass of this frame run on an internal stream concurrently
                                  with the previous frame's trailing a-trous levels.  0: everything is ordered on `stream`. */
-    int   reserved[2];
+    float reproj_scale[2];    /* "next" row f4, paper-faithful reprojection: if > 0, the previous-frame clip
+                                 coordinate is divided by it before the ndc mapping: (tan(FOVY) * W / H, tan(FOVY)) =
+                                 (pixelLength.x * W / 2, pixelLength.y * H / 2) makes the reprojection exact for any field
+                                 of view and aspect ratio.  0 = the reference's mapping (src/denoise.cu:202-203: "no
+                                 tan(fov), no aspect", exact only for tan(FOVY) = 1 and W = H; at 16:9 a static camera
+                                 keeps its history on ~16 % of the pixels) */
 } SvgfParams;
 
 #define SVGF_MAX_LEVELS 10

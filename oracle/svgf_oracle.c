@@ -203,7 +203,7 @@ static int reproj_valid(int W, int H, int p, float qx, float qy,
 static void backproject_pixel(int x, int y, float *variance_out, const int *hl, int *hl_upd,
                               const float *mom_hist, const float *col_hist, float *mom_acc, float *col_acc,
                               const float *cur_col, const SvgfGBufferTexel *cur_g, const SvgfGBufferTexel *prev_g,
-                              const float *M, int W, int H, float ca_min, float ma_min)
+                              const float *M, int W, int H, float ca_min, float ma_min, float rsx, float rsy)
 {
     const int p = x + y * W;
     const int N = hl[p];                                   /* at the CURRENT pixel (:194) */
@@ -221,6 +221,9 @@ static void backproject_pixel(int x, int y, float *variance_out, const int *hl, 
         }
         /* no tan(fov), no aspect (:202-207) */
         float clipx = vs[0] / vs[2], clipy = vs[1] / vs[2];
+        /* SvgfParams::reproj_scale: not in the reference; 0 keeps its mapping */
+        if (rsx > 0.0f) clipx = clipx / rsx;
+        if (rsy > 0.0f) clipy = clipy / rsy;
         float ndcx = -clipx * 0.5f + 0.5f, ndcy = -clipy * 0.5f + 0.5f;
         float prevx = ndcx * (float)W - 0.5f, prevy = ndcy * (float)H - 0.5f;
         float fx = floorf(prevx), fy = floorf(prevy);
@@ -291,12 +294,13 @@ static void backproject_pixel(int x, int y, float *variance_out, const int *hl, 
     variance_out[p] = 100.0f;
 }
 
-void svgf_oracle_backproject(float *variance_out, const int *history_length, int *history_length_update,
-                             const float *moment_history, const float *color_history,
-                             float *moment_acc, float *color_acc,
-                             const float *current_color, const SvgfGBufferTexel *current_gbuffer,
-                             const SvgfGBufferTexel *prev_gbuffer, const float prev_viewmat[16],
-                             int W, int H, float color_alpha_min, float moment_alpha_min, int nthreads)
+void svgf_oracle_backproject_ex(float *variance_out, const int *history_length, int *history_length_update,
+                                const float *moment_history, const float *color_history,
+                                float *moment_acc, float *color_acc,
+                                const float *current_color, const SvgfGBufferTexel *current_gbuffer,
+                                const SvgfGBufferTexel *prev_gbuffer, const float prev_viewmat[16],
+                                int W, int H, float color_alpha_min, float moment_alpha_min, int nthreads,
+                                float reproj_sx, float reproj_sy)
 {
     (void)nthreads;
 #ifdef _OPENMP
@@ -306,7 +310,19 @@ void svgf_oracle_backproject(float *variance_out, const int *history_length, int
         for (int x = 0; x < W; x++)
             backproject_pixel(x, y, variance_out, history_length, history_length_update, moment_history,
                               color_history, moment_acc, color_acc, current_color, current_gbuffer,
-                              prev_gbuffer, prev_viewmat, W, H, color_alpha_min, moment_alpha_min);
+                              prev_gbuffer, prev_viewmat, W, H, color_alpha_min, moment_alpha_min, reproj_sx, reproj_sy);
+}
+
+void svgf_oracle_backproject(float *variance_out, const int *history_length, int *history_length_update,
+                             const float *moment_history, const float *color_history,
+                             float *moment_acc, float *color_acc,
+                             const float *current_color, const SvgfGBufferTexel *current_gbuffer,
+                             const SvgfGBufferTexel *prev_gbuffer, const float prev_viewmat[16],
+                             int W, int H, float color_alpha_min, float moment_alpha_min, int nthreads)
+{   /* the reference's BackProjection */
+    svgf_oracle_backproject_ex(variance_out, history_length, history_length_update, moment_history, color_history,
+                               moment_acc, color_acc, current_color, current_gbuffer, prev_gbuffer, prev_viewmat, W, H,
+                               color_alpha_min, moment_alpha_min, nthreads, 0.0f, 0.0f);
 }
 
 /* ------------------------------------------------------------------------------------------------ */
@@ -441,9 +457,10 @@ int svgf_oracle_denoise(oracle_ctx *c, float *out, const float *in, const SvgfGB
 
     /* 1) temporal accumulation or constant variance (:360-371) */
     if (p->temporal_enable) {
-        svgf_oracle_backproject(c->variance, c->history_length, c->history_length_update, c->moment_history,
+        svgf_oracle_backproject_ex(c->variance, c->history_length, c->history_length_update, c->moment_history,
                                 c->color_history, c->moment_acc, c->color_acc, in, g, c->gbuffer_prev,
-                                c->view_prev, W, H, p->color_alpha, p->moment_alpha, c->nthreads);
+                                c->view_prev, W, H, p->color_alpha, p->moment_alpha, c->nthreads,
+                                p->reproj_scale[0], p->reproj_scale[1]);
         memcpy(c->color_history, c->color_acc, n * 3 * sizeof(float));
     } else {
         for (size_t k = 0; k < n; k++) c->variance[k] = 10.0f;

@@ -53,6 +53,14 @@ void svgf_oracle_backproject(float *variance_out, const int *history_length, int
                              const float *current_color, const SvgfGBufferTexel *current_gbuffer,
                              const SvgfGBufferTexel *prev_gbuffer, const float prev_viewmat[16],
                              int W, int H, float color_alpha_min, float moment_alpha_min, int nthreads);
+/* the same with SvgfParams::reproj_scale (extension); (0, 0) == svgf_oracle_backproject */
+void svgf_oracle_backproject_ex(float *variance_out, const int *history_length, int *history_length_update,
+                             const float *moment_history, const float *color_history,
+                             float *moment_acc, float *color_acc,
+                             const float *current_color, const SvgfGBufferTexel *current_gbuffer,
+                             const SvgfGBufferTexel *prev_gbuffer, const float prev_viewmat[16],
+                             int W, int H, float color_alpha_min, float moment_alpha_min, int nthreads,
+                                float reproj_sx, float reproj_sy);
 
 /* GetViewMatrix, src/denoise.cu:342-347: inverse of the column-major matrix [right|up|view|position]. */
 void svgf_oracle_view_matrix(const SvgfCamera *cam, float out_colmajor[16]);

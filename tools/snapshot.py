@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Visual QA: produce -> denoise -> display-pack N frames on the device, save frame N-1 side by side
 (1-spp | denoised, as the reference's viewer shows them) as a PNG with svgf_save_png.
-usage: snapshot.py [--size 640x360] [--frames 16] [--moving] [--out gpurun_out/side_by_side.png]"""
+usage: snapshot.py [--size 640x360] [--frames 16] [--moving] [--exact-reprojection] [--out gpurun_out/side_by_side.png]"""
 import argparse
 import os
 import sys
@@ -18,6 +18,7 @@ def main():
     ap.add_argument("--size", default="640x360")
     ap.add_argument("--frames", type=int, default=16)
     ap.add_argument("--moving", action="store_true")
+    ap.add_argument("--exact-reprojection", action="store_true", help="SvgfParams::reproj_scale = (tan(fovy) W/H, tan(fovy))")
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "side_by_side.png"))
     a = ap.parse_args()
     import torch
@@ -25,6 +26,9 @@ def main():
     W, H = map(int, a.size.split("x"))
     den = pkg.Denoiser(W, H)
     params = pkg.reference_defaults().set(temporal_enable=1, spatial_enable=1, atrous_nlevel=5, history_level=1)
+    if a.exact_reprojection:
+        plx, ply = pkg.synth._pixel_length(W, H, 45.0)
+        params.reproj_scale[0], params.reproj_scale[1] = float(plx) * W / 2.0, float(ply) * H / 2.0
     rgb = torch.empty((H, W, 3), dtype=torch.float32, device="cuda")
     gb = torch.empty((H * W * 52,), dtype=torch.uint8, device="cuda")
     out = torch.empty((H, W, 3), dtype=torch.float32, device="cuda")
