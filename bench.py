@@ -34,11 +34,11 @@ FRAME_BYTES_PER_PIXEL = 404.0      # temporal 124 + 5 x 56
 HBM_PEAK_GBS = 8000.0              # MI355X_MICROARCH.md: 8 TB/s spec
 
 
-def cpu_baseline(pkg, frames, params, budget_s=25.0):
+def cpu_baseline(pkg, frames, params, budget_s=25.0, threads=None, what="full-SVGF"):
     """CPU oracle (oracle/svgf_oracle.c, OpenMP) on the same workload, bounded sample."""
     orc = ge.load_oracle()
     cores = os.cpu_count() or 1
-    threads = min(cores, 64)
+    threads = min(cores, 64) if threads is None else threads
     o = orc.Oracle(pkg, W, H, threads=threads)
     t_all, n = 0.0, 0
     t_start = time.perf_counter()
@@ -53,7 +53,7 @@ def cpu_baseline(pkg, frames, params, budget_s=25.0):
             break
     o.free()
     return {"value": round(W * H / (t_all / n) / 1e6, 3), "unit": "Mpixels/s", "cores": threads, "kind": "port",
-            "sample": f"{n} steady-state frames of the same 1920x1080 full-SVGF workload, oracle/svgf_oracle.c "
+            "sample": f"{n} steady-state frames of the same {W}x{H} {what} workload, oracle/svgf_oracle.c "
                       f"(gcc -O2, OpenMP over rows, {threads} threads of {cores} host cores)"}
 
 
@@ -63,9 +63,10 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--config", default="1080p-static", choices=["1080p-static", "1080p-moving", "4k-static", "4k-moving"],
+    ap.add_argument("--config", default="1080p-static", choices=["1080p-static", "1080p-moving", "4k-static", "4k-moving", "config1"],
                     help="1080p-static = BASELINE configs[1] (the default, the headline metric); 1080p-moving = configs[2] "
-                         "(64-frame moving-camera sequence); 4k-static = configs[3]; 4k-moving = the same at 3840x2160")
+                         "(64-frame moving-camera sequence); 4k-static = configs[3]; 4k-moving = the same at 3840x2160; config1 = "
+                         "configs[0]: 800x800, temporal off, one a-trous level, CPU leg single-threaded")
     ap.add_argument("--host-inputs", action="store_true",
                     help="render the synthetic frames with numpy and upload them (default: the device-side producer, "
                          "svgf_synth_render, SURVEY.md 8f row f1; both give the same frames bit for bit)")
@@ -91,6 +92,8 @@ def main():
     global W, H
     if a.config.startswith("4k"):
         W, H = 3840, 2160
+    if a.config == "config1":
+        W, H = 800, 800
     moving = a.config.endswith("moving")
     # one rank per node builds (normally a no-op: the libraries are prebuilt in-tree); the others wait
     if local_rank == 0:
@@ -100,6 +103,8 @@ def main():
     pkg = ge.load_package()
     params = pkg.reference_defaults().set(temporal_enable=1, spatial_enable=1, atrous_nlevel=NLEVEL, history_level=1,
                                           inputs_ready=1)   # inputs are resident in HBM before each call
+    if a.config == "config1":   # BASELINE configs[0]: the reference's own CPU-runnable case
+        params.set(temporal_enable=0, atrous_nlevel=1)
 
     # every rank owns one independent sequence (its own seed); 4 distinct noisy frames, static camera, resident in HBM
     seq = pkg.farm.shard(world, world, rank)[0]
@@ -152,6 +157,8 @@ def main():
     # the GPU with the next frame's temporal pass; events around every kernel of 16 frames
     iso_params = pkg.reference_defaults().set(temporal_enable=1, spatial_enable=1, atrous_nlevel=NLEVEL, history_level=1,
                                               inputs_ready=0)
+    if a.config == "config1":
+        iso_params.set(temporal_enable=0, atrous_nlevel=1)
     den.profile_stride(1)
     den.profile_enable(16)
     for i in range(16):
@@ -173,14 +180,18 @@ def main():
         iso_us = float(np.mean(iso_atrous_ms)) * 1e3
         iso_gbs = ATROUS_BYTES_PER_PIXEL * W * H / (iso_us * 1e-6) / 1e9
         line = {
-            "metric": "SVGF Mpixels/s (full pipeline) at 1080p; a-trous HBM GB/s vs roofline" if not a.config.startswith("4k") else "SVGF Mpixels/s (full pipeline) at 4K; a-trous HBM GB/s vs roofline",
+            "metric": ("SVGF Mpixels/s (one non-temporal level, BASELINE configs[0]) at 800x800; a-trous HBM GB/s vs roofline" if a.config == "config1"
+                       else "SVGF Mpixels/s (full pipeline) at 4K; a-trous HBM GB/s vs roofline" if a.config.startswith("4k")
+                       else "SVGF Mpixels/s (full pipeline) at 1080p; a-trous HBM GB/s vs roofline"),
             "value": round(value, 2), "unit": "Mpixels/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(dt / a.steps * 1e3, 5), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"cornell-like {W}x{H}, full SVGF (temporal + 5 a-trous levels, history_level 1), "
+            "config": {"workload": (f"cornell-like {W}x{H}, variance fill + ONE a-trous level (temporal off), " if a.config == "config1" else
+                                    f"cornell-like {W}x{H}, full SVGF (temporal + 5 a-trous levels, history_level 1), ")
                                    + ("moving camera, 64-frame sequence replayed" if moving else "static camera, steady-state history")
                                    + "; one independent sequence per GPU", "name": a.config,
-                       "width": W, "height": H, "atrous_levels": NLEVEL, "parallelism": f"replicas{world}"},
+                       "width": W, "height": H, "atrous_levels": 1 if a.config == "config1" else NLEVEL,
+                       "parallelism": f"replicas{world}"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, profiles/pmc_traffic.json (FETCH x2 per MI355X_MICROARCH.md)",
@@ -192,17 +203,22 @@ def main():
                                       "frac": round(iso_gbs / HBM_PEAK_GBS, 4), "launches_timed": len(iso_atrous_ms)},
                          # the secondary limiter.  24 taps x (2 v_sqrt + 1 v_exp) + 5 (centre, normalisation) per pixel-level
                          "transcendental_gops_isolated": round(77 * W * H / (iso_us * 1e-6) / 1e9, 1)},
-            "kernels_us": {"temporal": round(float(np.mean(temporal_ms)) * 1e3, 2), "atrous_level_mean": round(a_ms * 1e3, 2)},
-            "frame_algorithmic_gbs": round(FRAME_BYTES_PER_PIXEL * W * H / (dt / a.steps) / 1e9 / world * 1.0, 1),
+            "kernels_us": {"temporal": round(float(np.mean(temporal_ms)) * 1e3, 2) if temporal_ms else None,
+                           "atrous_level_mean": round(a_ms * 1e3, 2)},
+            "frame_algorithmic_gbs": round((ATROUS_BYTES_PER_PIXEL if a.config == "config1" else FRAME_BYTES_PER_PIXEL)
+                                           * W * H / (dt / a.steps) / 1e9 / world * 1.0, 1),
         }
         if a.config != "1080p-static":
             line["roofline"]["traffic"] = None      # the committed PMC passes are for the 1080p-static workload
-        if world == 1 and not a.no_cpu_baseline and a.config == "1080p-static":
+        if world == 1 and not a.no_cpu_baseline and a.config in ("1080p-static", "config1"):
             if frames is None:   # bring the device-produced frames to the host for the CPU leg
                 frames = [(d_in[f].cpu().numpy(), d_g[f].cpu().numpy().view(pkg.synth.GBUFFER_DTYPE).reshape(H, W), cam_dicts[f])
                           for f in range(min(nsrc, 4))]
             host_frames = [(f[0], f[1], f[2]) for f in frames]
-            line["cpu_baseline"] = cpu_baseline(pkg, host_frames, params)
+            if a.config == "config1":   # "single-threaded" is how BASELINE.json words this configuration
+                line["cpu_baseline"] = cpu_baseline(pkg, host_frames, params, threads=1, what="one-level non-temporal")
+            else:
+                line["cpu_baseline"] = cpu_baseline(pkg, host_frames, params)
         print(json.dumps(line), flush=True)
     den.free()
     if dist is not None:

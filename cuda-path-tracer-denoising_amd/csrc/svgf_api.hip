@@ -364,7 +364,9 @@ extern "C" int svgf_denoise(svgf_ctx *c, void *out_rgb_dev, const void *in_rgb_d
     //    pass runs on the context's side stream as soon as the level feeding the colour history of the PREVIOUS frame
     //    is done, i.e. concurrently with that frame's remaining levels.  The temporal pass is HBM-bound and the a-trous
     //    levels are VALU-bound, so the two kernels share the CUs well.
-    const bool overlap = (p->inputs_ready != 0);
+    //    Only the temporal pass is worth a second stream: the constant-variance fill of the non-temporal mode is a
+    //    few microseconds, less than the cross-stream event hand-off costs.
+    const bool overlap = (p->inputs_ready != 0) && (p->temporal_enable != 0);
     int acc = -1;
     for (int k = 0; k < 4; k++) if (k != c->hist && !((c->inflight_mask >> k) & 1u)) { acc = k; break; }
     if (acc < 0) { snprintf(c->err, sizeof(c->err), "svgf_denoise: internal error, no free colour plane"); return SVGF_ERR_HIP; }
