@@ -188,6 +188,10 @@ __global__ __launch_bounds__(TX * ROWS + loader_threads(TX, ROWS)) SVGF_STRIP_AT
     const int tid = threadIdx.x;
 
     if (tid == 0) *nan_seen = 0;
+    // the one kernel argument only the compute waves use: fetch it now rather than behind the prologue barrier
+    // (an s_load from the kernarg segment that misses the scalar cache costs several hundred cycles)
+    float sigma_c = a.sigma_c;
+    asm volatile("" : "+s"(sigma_c));
 
     // ring slot of lattice row br (>= b0-2).  R is 8 for ROWS = 2 (a mask); for other R the iteration loops keep the
     // slot of row bc-2 in `ring_base` (wave-uniform, advanced by ROWS per iteration) and wrap small offsets from it.
@@ -384,22 +388,6 @@ __global__ __launch_bounds__(TX * ROWS + loader_threads(TX, ROWS)) SVGF_STRIP_AT
         }
     };
 
-    // ---- prologue: every thread helps stage rows b0-2 .. b0+ROWS+1 and the blur rows of iteration 0;
-    //      loader group 1 also puts the loads of iteration 1 in flight ----
-    {
-        constexpr int M = ((4 + ROWS) * RW + NT - 1) / NT;
-        Px px[M];
-        rows_load(px, b0 - 2, 4 + ROWS, tid, NT);
-        constexpr int MB = (ROWS * 2 * BW + NT - 1) / NT;
-        float bv[MB];
-        blur_load(bv, b0, tid, NT);
-        rows_store(px);
-        if (a.blur_variance) blur_store(bv, 0, tid, NT);
-    }
-    if (kLoaderGroups == 1) { if (is_loader) loader_issue(1); }     // single group: commit, then re-issue, every iteration
-    else if (is_loader && lgroup >= 1) loader_issue(lgroup);        // iterations 1 .. kLoaderGroups-1: issue before the first barrier
-    __syncthreads();
-
     // in-kernel timeline (tools, profiles/r01_strip_phase_timeline*.log): compiled in only with -DSVGF_STRIP_TIMELINE,
     // because each stamp is a branch that splits the iteration into basic blocks the scheduler cannot move loads across
     int dbg_it = 0;
@@ -412,15 +400,42 @@ __global__ __launch_bounds__(TX * ROWS + loader_threads(TX, ROWS)) SVGF_STRIP_AT
 #endif
     };
 
+    // ---- prologue: every thread helps stage rows b0-2 .. b0+ROWS+1 and the blur rows of iteration 0;
+    //      loader group 1 also puts the loads of iteration 1 in flight ----
+    {
+        constexpr int M = ((4 + ROWS) * RW + NT - 1) / NT;
+        Px px[M];
+        stamp(7);
+        rows_load(px, b0 - 2, 4 + ROWS, tid, NT);
+        constexpr int MB = (ROWS * 2 * BW + NT - 1) / NT;
+        float bv[MB];
+        blur_load(bv, b0, tid, NT);
+        stamp(1);
+        rows_store(px);
+        if (a.blur_variance) blur_store(bv, 0, tid, NT);
+        stamp(4);
+    }
+    __syncthreads();
+
     if (is_loader) {
         // ================================ loader waves ================================
+        // The loads of iterations 1 .. kLoaderGroups-1 are issued at the top of iteration 0, not in front of the
+        // prologue barrier: carrying loaded registers into the loop made the compiler copy them behind an
+        // s_waitcnt vmcnt(0) that held the whole workgroup at the first barrier for a global-load latency.  Group 1
+        // therefore issues and commits iteration 1's rows within iteration 0 (the loads land well inside its ~3 us).
         __builtin_amdgcn_s_setprio(SVGF_LOADER_PRIO);
         int it = 0;
         for (int bc = b0; bc < b1; bc += ROWS, it++, dbg_it++) {
             stamp(0);
-            if (kLoaderGroups == 1) { loader_commit(it + 1); loader_issue(it + 2); }
-            else if ((it + 1) % kLoaderGroups == lgroup) loader_commit(it + 1);     // issued kLoaderGroups-1 iterations ago
-            else if (it % kLoaderGroups == lgroup) loader_issue(it + kLoaderGroups);
+            if (kLoaderGroups == 1) {                                   // single group: commit, then re-issue, every iteration
+                if (it == 0) loader_issue(1);
+                loader_commit(it + 1);
+                loader_issue(it + 2);
+            } else {
+                if (it == 0 && lgroup >= 1) loader_issue(lgroup);
+                if ((it + 1) % kLoaderGroups == lgroup) loader_commit(it + 1);      // issued kLoaderGroups-1 iterations ago
+                else if (it % kLoaderGroups == lgroup) loader_issue(it + kLoaderGroups);
+            }
             stamp(5);
             __syncthreads();
             stamp(6);
@@ -476,7 +491,7 @@ __global__ __launch_bounds__(TX * ROWS + loader_threads(TX, ROWS)) SVGF_STRIP_AT
             Centre c;
             c.nx_px = v2f{A.x, A.y}; c.ny_py = v2f{A.z, A.w}; c.nz_pz = v2f{B.x, B.y};
             c.lp = B.z;
-            c.kl = kLog2e * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(var) * a.sigma_c + 1e-6f);
+            c.kl = kLog2e * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(var) * sigma_c + 1e-6f);
             c.kn = kn; c.kx = kx;
             stamp(2);
 
@@ -699,6 +714,10 @@ hipError_t launch_cfg(const AtrousArgs &a, hipStream_t s)
             const int show[4] = { 0, nw - nlw - 1, nw - nlw, nw - 1 };
             for (int si = 0; si < 4; si++) {
                 const int w = show[si];
+                if (h[(w * 16) * 8 + 7])
+                    fprintf(stderr, "  wave %2d prologue: entry..loads issued %5llu, ..stored %6llu, ..first iteration %6llu\n", w,
+                            h[(w * 16) * 8 + 1] - h[(w * 16) * 8 + 7], h[(w * 16) * 8 + 4] - h[(w * 16) * 8 + 7],
+                            h[(w * 16) * 8 + 0] - h[(w * 16) * 8 + 7]);
                 for (int it = 0; it < 16 && h[(w * 16 + it) * 8]; it++) {
                     unsigned long long *t = &h[(w * 16 + it) * 8];
                     if (w >= nw - nlw)
