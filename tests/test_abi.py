@@ -72,3 +72,11 @@ def test_product_never_touches_the_oracle():
     import subprocess
     out = subprocess.run(["ldd", os.path.join(pk, "libsvgf_hip.so")], stdout=subprocess.PIPE, text=True).stdout
     assert "oracle" not in out
+    # nor do the tools: only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "tools")):
+        for f in files:
+            if f.endswith((".py", ".sh")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert "load_oracle" not in text and "svgf_oracle" not in text and "oracle_py" not in text, os.path.join(dirpath, f)
+    bench = open(os.path.join(ROOT, "bench.py")).read()
+    assert bench.count("load_oracle") == 1 and "def cpu_baseline" in bench      # one use, inside the cpu_baseline leg
