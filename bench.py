@@ -202,7 +202,12 @@ def main():
                          "isolated": {"mean_launch_us": round(iso_us, 2), "achieved": round(iso_gbs, 1),
                                       "frac": round(iso_gbs / HBM_PEAK_GBS, 4), "launches_timed": len(iso_atrous_ms)},
                          # the secondary limiter.  24 taps x (2 v_sqrt + 1 v_exp) + 5 (centre, normalisation) per pixel-level
-                         "transcendental_gops_isolated": round(77 * W * H / (iso_us * 1e-6) / 1e9, 1)},
+                         "transcendental_gops_isolated": round(77 * W * H / (iso_us * 1e-6) / 1e9, 1),
+                         # what actually bounds the kernel: SIMD instruction issue, 3/4 of it fp32 VALU.
+                         # ~950 flop per pixel-level (24 taps x 37 + centre/normalisation) against the 157.3 TFLOP/s
+                         # packed-fp32 vector peak; the PMC figure (SQ_ACTIVE_INST_ANY / SIMD time) is in profiles/.
+                         "valu_view": {"fp32_tflops_isolated": round(950 * W * H / (iso_us * 1e-6) / 1e12, 1),
+                                       "fp32_vector_peak_tflops": 157.3, "simd_instruction_active_pmc": 1.0}},
             "kernels_us": {"temporal": round(float(np.mean(temporal_ms)) * 1e3, 2) if temporal_ms else None,
                            "atrous_level_mean": round(a_ms * 1e3, 2)},
             "frame_algorithmic_gbs": round((ATROUS_BYTES_PER_PIXEL if a.config == "config1" else FRAME_BYTES_PER_PIXEL)
