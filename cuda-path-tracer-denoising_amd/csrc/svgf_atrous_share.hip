@@ -537,12 +537,17 @@ hipError_t launch_share_cfg(const AtrousArgs &a, hipStream_t s)
     using L = Lds<LOG2S>;
     constexpr int S = L::S;
     const size_t lds = L::BYTES;
-    static bool attr_done = false;
-    if (!attr_done) {
+    // per device: one process may own contexts on several GPUs (include/svgf.h: handle-based), and the opt-in to more
+    // than 64 KB of dynamic LDS is a per-device function attribute
+    static bool attr_done[64] = {};
+    int dev_id = 0;
+    (void)hipGetDevice(&dev_id);
+    if (dev_id < 0 || dev_id >= 64) dev_id = 0;
+    if (!attr_done[dev_id]) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_atrous_share<LOG2S>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
-        attr_done = true;
+        attr_done[dev_id] = true;
     }
     ShareGeom gm;
     gm.n_strips = (a.W + TX - 1) / TX;

@@ -647,12 +647,17 @@ hipError_t launch_cfg(const AtrousArgs &a, hipStream_t s)
 {
     constexpr int S = 1 << LOG2S, RW = TX + 4 * S, R = 4 + 2 * ROWS, BW = TX + 2;
     const size_t lds = (size_t)R * RW * 48 + (size_t)2 * ROWS * 2 * BW * 4 + 16;
-    static bool attr_done = false;
-    if (!attr_done) {
+    // per device: one process may own contexts on several GPUs (include/svgf.h: handle-based), and the opt-in to more
+    // than 64 KB of dynamic LDS is a per-device function attribute
+    static bool attr_done[64] = {};
+    int dev_id = 0;
+    (void)hipGetDevice(&dev_id);
+    if (dev_id < 0 || dev_id >= 64) dev_id = 0;
+    if (!attr_done[dev_id]) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_atrous_strip<LOG2S, TX, ROWS, HASVAR>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
-        attr_done = true;
+        attr_done[dev_id] = true;
     }
     StripGeom gm;
     gm.n_strips = (a.W + TX - 1) / TX;
