@@ -678,13 +678,14 @@ hipError_t launch_cfg(const AtrousArgs &a, hipStream_t s)
     const int capacity = n_cu * bpc;
     int best_L = nb_max;
     long best_cost = -1;
+    static const int fixed_rows = getenv("SVGF_STRIP_FIXED_ROWS") ? atoi(getenv("SVGF_STRIP_FIXED_ROWS")) : 8;   // tuning only
     for (int L = ROWS * 4; L <= nb_max + ROWS; L++) {        // L need not be a multiple of ROWS: the last iteration idles rows
         const int segs_l = (nb_max + L - 1) / L;
         // (phase, segment) groups are dealt round-robin to the 8 XCDs (blockIdx % 8), all strips of a group to the same
         // XCD: the busiest XCD, with ceil(groups / 8) groups, sets the number of rounds
         const long blocks_xcd = (long)gm.n_strips * ((S * segs_l + 7) / 8);
         const long rounds = (blocks_xcd + capacity / 8 - 1) / (capacity / 8);
-        const long cost = rounds * ((L + ROWS - 1) / ROWS * ROWS + 8);
+        const long cost = rounds * ((L + ROWS - 1) / ROWS * ROWS + fixed_rows);
         if (best_cost < 0 || cost <= best_cost) { best_cost = cost; best_L = L; }   // ties: fewer, longer workgroups
     }
     if (const char *e = getenv("SVGF_STRIP_SEGROWS")) { int v = atoi(e); if (v > 0) best_L = v; }
