@@ -67,6 +67,8 @@ def main():
                     help="1080p-static = BASELINE configs[1] (the default, the headline metric); 1080p-moving = configs[2] "
                          "(64-frame moving-camera sequence); 4k-static = configs[3]; 4k-moving = the same at 3840x2160; config1 = "
                          "configs[0]: 800x800, temporal off, one a-trous level, CPU leg single-threaded")
+    ap.add_argument("--kernel-variant", type=int, default=0,
+                    help="SvgfParams::kernel_variant (0 = the library's default choice; 2 strip, 4 lane-marching kernel ...)")
     ap.add_argument("--host-inputs", action="store_true",
                     help="render the synthetic frames with numpy and upload them (default: the device-side producer, "
                          "svgf_synth_render, SURVEY.md 8f row f1; both give the same frames bit for bit)")
@@ -103,6 +105,7 @@ def main():
     pkg = ge.load_package()
     params = pkg.reference_defaults().set(temporal_enable=1, spatial_enable=1, atrous_nlevel=NLEVEL, history_level=1,
                                           inputs_ready=1)   # inputs are resident in HBM before each call
+    params.set(kernel_variant=a.kernel_variant)
     if a.config == "config1":   # BASELINE configs[0]: the reference's own CPU-runnable case
         params.set(temporal_enable=0, atrous_nlevel=1)
 
@@ -157,6 +160,7 @@ def main():
     # the GPU with the next frame's temporal pass; events around every kernel of 16 frames
     iso_params = pkg.reference_defaults().set(temporal_enable=1, spatial_enable=1, atrous_nlevel=NLEVEL, history_level=1,
                                               inputs_ready=0)
+    iso_params.set(kernel_variant=a.kernel_variant)
     if a.config == "config1":
         iso_params.set(temporal_enable=0, atrous_nlevel=1)
     den.profile_stride(1)

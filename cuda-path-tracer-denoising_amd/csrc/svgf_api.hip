@@ -339,7 +339,7 @@ extern "C" int svgf_denoise(svgf_ctx *c, void *out_rgb_dev, const void *in_rgb_d
         snprintf(c->err, sizeof(c->err), "svgf_denoise: atrous_nlevel %d outside 0..%d", p->atrous_nlevel, SVGF_MAX_LEVELS);
         return SVGF_ERR_INVALID_ARG;
     }
-    if (p->kernel_variant < 0 || p->kernel_variant > 3) {
+    if (p->kernel_variant < 0 || p->kernel_variant > 4) {
         snprintf(c->err, sizeof(c->err), "svgf_denoise: kernel_variant %d unknown", p->kernel_variant);
         return SVGF_ERR_INVALID_ARG;
     }
@@ -450,6 +450,8 @@ extern "C" int svgf_denoise(svgf_ctx *c, void *out_rgb_dev, const void *in_rgb_d
                 }
             }
             if (strip && p->kernel_variant == 3 && atrous_share_supported(a)) LAUNCH(SVGF_KERNEL_ATROUS, launch_atrous_share(a, s));
+            else if (strip && (p->kernel_variant == 4 || p->kernel_variant == 0) && atrous_lane_supported(a))
+                LAUNCH(SVGF_KERNEL_ATROUS, launch_atrous_lane(a, s));      // steps 2, 4, 8: symmetric terms evaluated once
             else if (strip) LAUNCH(SVGF_KERNEL_ATROUS, launch_atrous_strip(a, s));
             else            LAUNCH(SVGF_KERNEL_ATROUS, launch_atrous_gather(a, s));
             if (hist_final && dst >= 0) c->inflight_mask |= 1u << dst;   // written after the history is final

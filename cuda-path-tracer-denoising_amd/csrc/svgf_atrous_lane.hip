@@ -1,0 +1,687 @@
+// svgf_atrous_lane.hip — a-trous level with the symmetric part of every tap evaluated ONCE, for S = 2, 4, 8 (gfx950).
+//
+// Same result as svgf_atrous_strip.hip (one level of reference ATrousFilter, src/denoise.cu:77-170, snapshot variance)
+// and the same staging machinery (LDS ring filled by loader waves, one barrier per iteration).  What changes is who
+// evaluates what.  The geometric part of the edge-stopping exponent,
+//     t(p,q) = -log2 h + kn |n_p - n_q| + kx |x_p - x_q|,
+// is symmetric, and every pair (p,q) is a tap of p and a tap of q; the strip kernel pays 6 packed + 2 scalar VALU and
+// 2 v_sqrt for it twice.  Here a LANE owns one lattice column and marches down its rows, one row per iteration:
+//     * at row b it evaluates t for its 12 FORWARD partners only (rows b+1, b+2 and the two right-hand neighbours in
+//       row b) and uses them for its own forward taps;
+//     * it keeps the terms of rows b+1 / b+2 in registers for one / two iterations, and its 12 BACKWARD taps take
+//       their t from the lane that owns the partner column: partner (x + i, b - j) published it j iterations ago as
+//       its forward term (-i, +j), so it arrives by a DPP wave shift of |i| lanes (v_mov_b32_dpp wave_shr/wave_shl:1,
+//       which the compiler folds into the consuming VALU op where it can).
+// 12 geometry evaluations per output pixel instead of 24, no extra LDS traffic, no extra barrier.
+//
+// For the partner of column x +- i to be lane +- i, the 64 lanes of a wave hold 64 consecutive columns of ONE x-phase
+// (pixel columns x, x+S, x+2S, ...): the LDS ring stores every row phase-major ([phase][lattice column], 48-byte
+// records, so tap addresses are base + i*48 and stay bank-conflict-free), the loaders scatter into that layout, and
+// the outermost two lanes on either side of a wave are halo lanes (their shifted-in terms are garbage, they store
+// nothing): a wave produces 60 columns, a workgroup 8 waves x 60 x ... = 480 contiguous pixel columns.
+//     S = 2: 4 waves per x-phase     S = 4: 2 waves per x-phase     S = 8: 1 wave per x-phase
+// S >= 16 would need several phases inside one wave (28 or 12 useful lanes out of 32 / 16): those levels stay on the
+// strip kernel.
+//
+// LDS: ring 6 rows (b-2 .. b+2 live, b+3 incoming) x (480 + 4S) pixels x 48 B = 140.5 .. 147.5 KB, + pre-blur rows.
+#include "svgf_kernels.h"
+
+#include <cstdio>
+#include <cstdlib>
+#include <type_traits>
+
+#ifndef SVGF_LANE_G2
+#define SVGF_LANE_G2 2      // where the second forward row's geometry is read: 0 one row ahead, 1 mid-row, 2 not ahead
+#endif
+#ifndef SVGF_LANE_G1
+#define SVGF_LANE_G1 1      // first forward row's geometry read one row ahead (1) or not (0)
+#endif
+
+namespace {
+
+constexpr float kLog2e = 1.44269504088896340736f;
+constexpr int NWC = 8;                       // compute waves
+constexpr int LOUT = 60;                     // output lanes per wave (2 halo lanes either side)
+constexpr int TXO = NWC * LOUT;              // 480 output pixel columns per workgroup, for every S
+constexpr int kLoaderGroups = 2, kLoaderGroup = 128, kLoaderThreads = kLoaderGroups * kLoaderGroup;
+constexpr int NC = NWC * 64, NT = NC + kLoaderThreads;
+constexpr int PXB = 48;
+constexpr int R = 6;                         // ring slots: rows b-2 .. b+2 live, b+3 incoming
+constexpr int BW = TXO + 2;                  // pre-blur row: pixel columns x0-1 .. x0+TXO
+
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+struct LaneGeom {
+    int n_strips, n_segs, seg_rows, n_groups;
+    float kn, kx;
+};
+
+struct Px {
+    float4 cv;
+    float nx, ny, nz, px, py, pz;
+    int lds_off;   // byte offset of the record in the ring; bit 31 or bit 30 set = out-of-image pixel
+};
+
+__device__ __forceinline__ float lum_f64(float r, float g, float b)
+{   // reference luminance: double products, rounded once to float (src/denoise.cu:121,138)
+    double l = 0.2126 * (double)r + 0.7152 * (double)g;
+    l = l + 0.0722 * (double)b;
+    return (float)l;
+}
+
+__device__ __forceinline__ constexpr float neg_log2_binom(int i)
+{   // -log2 of the 5-tap binomial [1 4 6 4 1]/16
+    return (i == 0) ? 1.4150374992788437f : ((i == 1 || i == -1) ? 2.0f : 4.0f);
+}
+
+// value of v in lane (self + K), K in -2 .. 2 (wave-wide; lanes shifted in from outside the wave read 0)
+template <int K>
+__device__ __forceinline__ float lane_from(float v)
+{
+    int x = __builtin_bit_cast(int, v);
+    if constexpr (K == 1 || K == 2) x = __builtin_amdgcn_update_dpp(0, x, 0x130, 0xf, 0xf, true);      // wave_shl:1
+    if constexpr (K == 2) x = __builtin_amdgcn_update_dpp(0, x, 0x130, 0xf, 0xf, true);
+    if constexpr (K == -1 || K == -2) x = __builtin_amdgcn_update_dpp(0, x, 0x138, 0xf, 0xf, true);    // wave_shr:1
+    if constexpr (K == -2) x = __builtin_amdgcn_update_dpp(0, x, 0x138, 0xf, 0xf, true);
+    return __builtin_bit_cast(float, x);
+}
+
+template <int LOG2S, bool HASVAR>
+__global__ __launch_bounds__(NT) void k_atrous_lane(AtrousArgs a, LaneGeom gm)
+{
+    constexpr int S = 1 << LOG2S;
+    constexpr int WPP = NWC / S;                 // waves per x-phase
+    constexpr int M = LOUT * WPP + 4;            // lattice columns per phase in the ring (2 halo either side)
+    constexpr int MP = (M * 12 % 64 == 0) ? M + 1 : M;   // padded so that consecutive phases do not start on the same LDS bank
+    constexpr int RW = S * M;                    // staged pixel columns = TXO + 4S
+    constexpr int ROWB = S * MP * PXB;           // bytes per ring row
+    constexpr int BM = (BW + S - 1) / S;         // pre-blur lattice columns per phase
+    constexpr int RING_BYTES = R * ROWB;
+    constexpr int BLUR_ROW = S * BM;             // floats per pre-blur row (phase-major)
+    constexpr int BLUR_BUF = 2 * BLUR_ROW;       // [y-1 | y+1]
+    static_assert(RW == TXO + 4 * S, "layout");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float *blur = reinterpret_cast<float *>(smem + RING_BYTES);           // [iteration parity][y-1 | y+1][phase][BM]
+    int *nan_seen = reinterpret_cast<int *>(smem + RING_BYTES + 2 * BLUR_BUF * 4);
+
+    // ---- work item: (strip, y-phase, segment) as in the strip kernel ----
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, kk = bid >> 3;
+    const int g = xcd + 8 * (kk / gm.n_strips);
+    const int strip = kk % gm.n_strips;
+    if (g >= gm.n_groups) return;
+    const int phase = g / gm.n_segs, seg = g % gm.n_segs;
+    const int W = a.W, H = a.H;
+    if (phase >= H) return;
+    const int nb = (H - phase + S - 1) >> LOG2S;
+    const int b0 = seg * gm.seg_rows;
+    const int b1 = min(b0 + gm.seg_rows, nb);
+    if (b0 >= b1) return;
+    const int x0 = strip * TXO;
+    const int tid = threadIdx.x;
+    if (tid == 0) *nan_seen = 0;
+    float sigma_c = a.sigma_c;
+    asm volatile("" : "+s"(sigma_c));
+
+    // ring slot of lattice row br: `ring_base` is the slot of row ring_b - 2 (wave-uniform, advanced once per iteration)
+    int ring_base = 0, ring_b = b0;
+    auto slot_of = [&](int br) {
+        int s = ring_base + (br - (ring_b - 2));      // in [0, 2R)
+        s -= (s >= R) ? R : 0;
+        return s;
+    };
+    auto slot_mod = [&](int br) { return (br - (b0 - 2)) % R; };
+    auto ring_advance = [&]() { ring_b += 1; ring_base += 1; ring_base -= (ring_base >= R) ? R : 0; };
+    // record of staged pixel column xi (0 .. RW-1) inside a ring row: phase-major
+    auto rec_of = [&](int xi) { return ((xi & (S - 1)) * MP + (xi >> LOG2S)) * PXB; };
+    // element of pre-blur pixel column xb (0 .. BW-1) inside a pre-blur row
+    auto bel_of = [&](int xb) { return (xb & (S - 1)) * BM + (xb >> LOG2S); };
+
+    // ---------------- staging (global -> registers -> LDS ring), branch-free, coordinates clamped ----------------
+    auto rows_load = [&](auto &px, int br_first, int nrows, int wi, int nw) {
+        constexpr int N = sizeof(px) / sizeof(px[0]);
+        const int total = nrows * RW;
+#pragma unroll
+        for (int m = 0; m < N; m++) {
+            const int idx = min(wi + m * nw, total - 1);
+            const int rr = idx / RW, xi = idx - rr * RW;
+            const int br = br_first + rr;
+            const int y = phase + (br << LOG2S);
+            const int xs = x0 - 2 * S + xi;
+            const bool ok = (br >= 0) && (y < H) && (xs >= 0) && (xs < W);
+            px[m].lds_off = (slot_mod(br) * ROWB + rec_of(xi)) | (ok ? 0 : (int)0x80000000);
+            const unsigned q = (unsigned)min(max(y, 0), H - 1) * (unsigned)W + (unsigned)min(max(xs, 0), W - 1);
+            px[m].cv = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(a.src) + q * 16u);
+            const float *n = reinterpret_cast<const float *>(reinterpret_cast<const char *>(a.nrm) + q * 12u);
+            const float *p = reinterpret_cast<const float *>(reinterpret_cast<const char *>(a.pos) + q * 12u);
+            px[m].nx = n[0]; px[m].ny = n[1]; px[m].nz = n[2];
+            px[m].px = p[0]; px[m].py = p[1]; px[m].pz = p[2];
+        }
+    };
+    auto rows_store = [&](const auto &px) {
+        constexpr int N = sizeof(px) / sizeof(px[0]);
+        const float inf = __builtin_huge_valf();
+#pragma unroll
+        for (int m = 0; m < N; m++) {
+            const bool ok = (unsigned)px[m].lds_off < 0x40000000u;
+            const float lum = lum_f64(px[m].cv.x, px[m].cv.y, px[m].cv.z);
+            const float mag = fabsf(px[m].nx) + fabsf(px[m].ny) + fabsf(px[m].nz) + fabsf(px[m].px) + fabsf(px[m].py) + fabsf(px[m].pz);
+            if (!(mag < inf)) *nan_seen = 1;
+            char *d = smem + (px[m].lds_off & 0x3fffffff);
+            *reinterpret_cast<float4 *>(d) = make_float4(px[m].nx, px[m].px, px[m].ny, px[m].py);
+            *reinterpret_cast<float4 *>(d + 16) = make_float4(px[m].nz, px[m].pz, ok ? lum : inf, 0.0f);
+            *reinterpret_cast<float4 *>(d + 32) = ok ? px[m].cv : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    // pre-blur rows y-1, y+1 of output row bo (3x3 variance blur, :102-118); element e = d * BW + xb
+    auto blur_load = [&](auto &v, int bo, int wi, int nw) {
+        constexpr int N = sizeof(v) / sizeof(v[0]);
+#pragma unroll
+        for (int m = 0; m < N; m++) {
+            const int e = wi + m * nw;
+            v[m] = 0.0f;
+            if (a.blur_variance && e < 2 * BW) {
+                const int d = e / BW, xb = e - d * BW;
+                const int y = phase + (bo << LOG2S) + (d ? 1 : -1);
+                const int xs = x0 - 1 + xb;
+                if (y >= 0 && y < H && xs >= 0 && xs < W && bo < b1) v[m] = a.src[(unsigned)y * (unsigned)W + (unsigned)xs].w;
+            }
+        }
+    };
+    auto blur_store = [&](const auto &v, int parity, int wi, int nw) {
+        constexpr int N = sizeof(v) / sizeof(v[0]);
+#pragma unroll
+        for (int m = 0; m < N; m++) {
+            const int e = wi + m * nw;
+            if (e < 2 * BW) {
+                const int d = e / BW, xb = e - d * BW;
+                blur[parity * BLUR_BUF + d * BLUR_ROW + bel_of(xb)] = v[m];
+            }
+        }
+    };
+
+    // ---------------- loader threads: per-thread invariants ----------------
+    constexpr int ML = (RW + kLoaderGroup - 1) / kLoaderGroup;
+    constexpr int MBL = (2 * BW + kLoaderGroup - 1) / kLoaderGroup;
+    const bool is_loader = (tid >= NC);
+    const int lgroup = is_loader ? (tid - NC) / kLoaderGroup : -1;
+    const int llane = is_loader ? (tid - NC) % kLoaderGroup : 0;
+    Px lpx[ML];
+    float lbv[MBL];
+    int l_xq[ML], l_lds[ML];
+    int b_voff[MBL], b_lds[MBL];      // b_voff < 0: element does not exist or its column is outside the image
+    bool b_d[MBL];
+    if (is_loader) {
+#pragma unroll
+        for (int m = 0; m < ML; m++) {
+            const int xi = min(llane + m * kLoaderGroup, RW - 1);
+            const int xs = x0 - 2 * S + xi;
+            l_xq[m] = min(max(xs, 0), W - 1);
+            l_lds[m] = rec_of(xi) | ((xs >= 0 && xs < W) ? 0 : 0x40000000);
+        }
+#pragma unroll
+        for (int m = 0; m < MBL; m++) {
+            const int e = llane + m * kLoaderGroup;
+            const int d = e / BW, xb = e - d * BW;
+            const int xs = x0 - 1 + xb;
+            b_d[m] = (d != 0);
+            b_lds[m] = (e < 2 * BW) ? (d * BLUR_ROW + bel_of(xb)) : -1;
+            b_voff[m] = (e < 2 * BW && xs >= 0 && xs < W) ? (xs * 16 + 12) : -1;
+        }
+    }
+    // iteration j outputs row b0 + j and newly needs lattice row b0 + j + 2
+    auto loader_issue = [&](int j) {
+        const int bo = b0 + j;
+        if (bo < b1) {
+            const int br = bo + 2;
+            const int y = phase + (br << LOG2S);
+            const int rowq = min(y, H - 1) * W;
+            const int ldsrow = (slot_of(br) * ROWB) | (y < H ? 0 : (int)0x80000000);
+#pragma unroll
+            for (int m = 0; m < ML; m++) {
+                const unsigned q = (unsigned)(rowq + l_xq[m]);
+                lpx[m].lds_off = ldsrow + l_lds[m];
+                lpx[m].cv = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(a.src) + q * 16u);
+                const float *n = reinterpret_cast<const float *>(reinterpret_cast<const char *>(a.nrm) + q * 12u);
+                const float *p = reinterpret_cast<const float *>(reinterpret_cast<const char *>(a.pos) + q * 12u);
+                lpx[m].nx = n[0]; lpx[m].ny = n[1]; lpx[m].nz = n[2];
+                lpx[m].px = p[0]; lpx[m].py = p[1]; lpx[m].pz = p[2];
+            }
+            if (a.blur_variance) {
+                const int ym = phase + (bo << LOG2S) - 1, yp = ym + 2;
+                const unsigned rm = (unsigned)(min(max(ym, 0), H - 1) * W) * 16u, rp = (unsigned)(min(max(yp, 0), H - 1) * W) * 16u;
+#pragma unroll
+                for (int m = 0; m < MBL; m++)
+                    lbv[m] = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(a.src) + (b_d[m] ? rp : rm) + (unsigned)max(b_voff[m], 12));
+            }
+        }
+    };
+    auto loader_commit = [&](int j) {
+        const int bo = b0 + j;
+        if (bo < b1) {
+            rows_store(lpx);
+            if (a.blur_variance) {
+                const int ym = phase + (bo << LOG2S) - 1, yp = ym + 2;
+                const bool okm = ym >= 0 && ym < H, okp = yp >= 0 && yp < H;
+                float *bb = blur + (j & 1) * BLUR_BUF;
+#pragma unroll
+                for (int m = 0; m < MBL; m++)
+                    if (b_lds[m] >= 0) bb[b_lds[m]] = ((b_d[m] ? okp : okm) && b_voff[m] >= 0) ? lbv[m] : 0.0f;
+            }
+        }
+    };
+
+    // ---------------- prologue: every thread helps stage rows b0-2 .. b0+2 and the pre-blur rows of iteration 0 ----------
+    {
+        constexpr int N = (5 * RW + NT - 1) / NT;
+        Px px[N];
+        rows_load(px, b0 - 2, 5, tid, NT);
+        constexpr int NB = (2 * BW + NT - 1) / NT;
+        float bv[NB];
+        blur_load(bv, b0, tid, NT);
+        rows_store(px);
+        if (a.blur_variance) blur_store(bv, 0, tid, NT);
+    }
+    __syncthreads();
+
+    if (is_loader) {
+        // ================================ loader waves (as in the strip kernel) ================================
+        __builtin_amdgcn_s_setprio(2);
+        int it = 0;
+        for (int bo = b0; bo < b1; bo++, it++) {
+            if (it == 0 && lgroup >= 1) loader_issue(lgroup);
+            if ((it + 1) % kLoaderGroups == lgroup) loader_commit(it + 1);
+            else if (it % kLoaderGroups == lgroup) loader_issue(it + kLoaderGroups);
+            __syncthreads();
+            ring_advance();
+        }
+        return;
+    }
+
+    // ================================ compute waves ================================
+    const int lane = tid & 63, wv = tid >> 6;
+    const int xph = wv / WPP;                       // x-phase of this wave
+    const int mcol = (wv % WPP) * LOUT + lane;      // lattice column inside the phase, 0 .. M-1
+    const int xi = xph + S * mcol;                  // staged pixel column
+    const int x = x0 - 2 * S + xi;                  // image column
+    const bool out_lane = (lane >= 2) && (lane < 2 + LOUT) && (x < W);
+    const float kn = gm.kn, kx = gm.kx;
+    // base of the lane's tap window: record of column mcol-2, so that tap i = 0..4 (offset i-2) sits at +i*PXB and every
+    // address is base + non-negative immediate (the ds_read offset field is unsigned)
+    const char *colbase = smem + (xph * MP + mcol - 2) * PXB;
+    // neighbours x-1, x+1 of the centre in its own ring row (other x-phases), and the 3x3 pre-blur elements
+    const int off_l = rec_of(max(xi - 1, 0)) + 44, off_r = rec_of(min(xi + 1, RW - 1)) + 44;
+    const int xb = min(max(xi - 2 * S + 1, 1), BW - 2);
+    const int be_l = bel_of(xb - 1), be_c = bel_of(xb), be_r = bel_of(xb + 1);
+
+    // geometry evaluation of one partner: (|dn|^2, |dx|^2) -> t
+    // (the centre is passed NEGATED: q + (-c) keeps the three differences on v_pk_add_f32; with q - c hipcc splits them)
+    auto geo = [&](const v4f &Aq, const v4f &Bq, const v2f &nc0, const v2f &nc1, const v2f &nc2) {
+        const v2f d0 = Aq.xy + nc0, d1 = Aq.zw + nc1, d2 = Bq.xy + nc2;
+        v2f t = d0 * d0;
+        t = __builtin_elementwise_fma(d1, d1, t);
+        return __builtin_elementwise_fma(d2, d2, t);
+    };
+
+    // forward terms kept across iterations: index 0..4 <-> partner column offset -2..+2
+    float pF1[5], pF2[5], ppF2[5];
+#pragma unroll
+    for (int i = 0; i < 5; i++) { pF1[i] = 0.0f; pF2[i] = 0.0f; ppF2[i] = 0.0f; }
+
+    // forward rows (j = +1, +2) of the centre in lattice row br: 10 evaluations -> F1, F2 (+ optional taps)
+    struct Acc { v2f rg, bv, ww; };
+    auto accumulate = [&](Acc &acc, const v4f &Cq, float w) {
+        if (HASVAR) {
+            v2f wv2;
+            wv2.x = w;
+            wv2.y = w * w;
+            acc.ww += wv2;
+            acc.rg = __builtin_elementwise_fma(Cq.xy, v2f{w, w}, acc.rg);
+            acc.bv = __builtin_elementwise_fma(Cq.zw, wv2, acc.bv);
+        } else {
+            acc.ww.x += w;
+            acc.rg = __builtin_elementwise_fma(Cq.xy, v2f{w, w}, acc.rg);
+            acc.bv.x = fmaf(Cq.z, w, acc.bv.x);
+        }
+    };
+
+    struct ColRow { v4f C[5]; float l[5]; };              // colour-only row: colour slot + luminance of the 5 taps
+    struct GeoRow { v4f A[5], B[5]; };                    // forward row: geometry slots (the colour slot is read mid-row)
+    struct OwnRow { v4f A[2], B[2], C[2], Cb[2]; float l[2]; };   // own row: +1, +2 full records; -1, -2 colour + luminance
+    auto load_col = [&](ColRow &r, int br) {
+        const char *rowp = colbase + slot_of(br) * ROWB;
+#pragma unroll
+        for (int i = 0; i < 5; i++) {
+            r.C[i] = *reinterpret_cast<const v4f *>(rowp + i * PXB + 32);
+            r.l[i] = reinterpret_cast<const v2f *>(rowp + i * PXB + 24)->x;      // {lum, pad}: 8-byte read
+        }
+    };
+    auto load_geo = [&](GeoRow &r, int br) {
+        const char *rowp = colbase + slot_of(br) * ROWB;
+#pragma unroll
+        for (int i = 0; i < 5; i++) {
+            r.A[i] = *reinterpret_cast<const v4f *>(rowp + i * PXB);
+            r.B[i] = *reinterpret_cast<const v4f *>(rowp + i * PXB + 16);
+        }
+    };
+    auto load_own = [&](OwnRow &r, int br) {
+        const char *rowp = colbase + slot_of(br) * ROWB;
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            r.A[k] = *reinterpret_cast<const v4f *>(rowp + (k + 3) * PXB);
+            r.B[k] = *reinterpret_cast<const v4f *>(rowp + (k + 3) * PXB + 16);
+            r.C[k] = *reinterpret_cast<const v4f *>(rowp + (k + 3) * PXB + 32);
+            r.Cb[k] = *reinterpret_cast<const v4f *>(rowp + (1 - k) * PXB + 32);
+            r.l[k] = reinterpret_cast<const v2f *>(rowp + (1 - k) * PXB + 24)->x;
+        }
+    };
+    auto do_col = [&](Acc &acc, const ColRow &r, const float (&tt)[5], float lp, float kl) {
+        float e[5], w[5];
+#pragma unroll
+        for (int i = 0; i < 5; i++) e[i] = fmaf(fabsf(r.l[i] - lp), kl, tt[i]);
+        __builtin_amdgcn_sched_barrier(0x100);
+#pragma unroll
+        for (int i = 0; i < 5; i++) w[i] = __builtin_amdgcn_exp2f(-e[i]);
+        __builtin_amdgcn_sched_barrier(0x100);
+#pragma unroll
+        for (int i = 0; i < 5; i++) accumulate(acc, r.C[i], w[i]);
+    };
+    auto do_geo = [&](Acc &acc, const GeoRow &r, int br, auto jtag, float (&F)[5], const v2f &c0, const v2f &c1,
+                      const v2f &c2, float lp, float kl, GeoRow *next, int br_next) {
+        constexpr int j = decltype(jtag)::value;
+        const char *rowp = colbase + slot_of(br) * ROWB;
+        v2f s2[5];
+        v4f Cq[5];
+        float lq[5];
+#pragma unroll
+        for (int i = 0; i < 5; i++) { s2[i] = geo(r.A[i], r.B[i], c0, c1, c2); lq[i] = r.B[i].z; }
+#pragma unroll
+        for (int i = 0; i < 5; i++) Cq[i] = *reinterpret_cast<const v4f *>(rowp + i * PXB + 32);
+        if (next) load_geo(*next, br_next);        // the next forward row's geometry, once this row's is consumed
+        __builtin_amdgcn_sched_barrier(0x100);
+        float dn[5], dx[5];
+#pragma unroll
+        for (int i = 0; i < 5; i++) {
+            dn[i] = __builtin_amdgcn_sqrtf(s2[i].x);
+            dx[i] = __builtin_amdgcn_sqrtf(s2[i].y);
+        }
+        __builtin_amdgcn_sched_barrier(0x100);
+        float e[5], w[5];
+#pragma unroll
+        for (int i = 0; i < 5; i++) {
+            float t = fmaf(dn[i], kn, neg_log2_binom(i - 2) + neg_log2_binom(j));
+            t = fmaf(dx[i], kx, t);
+            F[i] = t;
+            e[i] = fmaf(fabsf(lq[i] - lp), kl, t);
+        }
+        __builtin_amdgcn_sched_barrier(0x100);
+#pragma unroll
+        for (int i = 0; i < 5; i++) w[i] = __builtin_amdgcn_exp2f(-e[i]);
+        __builtin_amdgcn_sched_barrier(0x100);
+#pragma unroll
+        for (int i = 0; i < 5; i++) accumulate(acc, Cq[i], w[i]);
+    };
+
+    // end of a tap row: nothing of this row may sink below, no LDS read of a later row may rise above (keeps the live
+    // ranges of a row's 5 x 48 bytes of tap data from piling up: without it hipcc hoists every load of the iteration)
+    auto row_fence = [&](Acc &acc) {
+        float a0 = acc.rg.x, a1 = acc.rg.y, a2 = acc.bv.x, a3 = acc.bv.y, a4 = acc.ww.x, a5 = acc.ww.y;
+        asm volatile("" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5) : : "memory");
+        acc.rg = v2f{a0, a1}; acc.bv = v2f{a2, a3}; acc.ww = v2f{a4, a5};
+    };
+
+    // ---- warm-up: rows b0-2 and b0-1 publish their forward terms (no output, no new ring rows needed) ----
+#pragma unroll 1
+    for (int bw = b0 - 2; bw < b0; bw++) {
+        const char *rowc = colbase + slot_of(bw) * ROWB + 2 * PXB;
+        const v4f A = *reinterpret_cast<const v4f *>(rowc);
+        const v4f B = *reinterpret_cast<const v4f *>(rowc + 16);
+        float F1[5], F2[5];
+#pragma unroll
+        for (int j = 1; j <= 2; j++) {
+            const char *rowp = colbase + slot_of(bw + j) * ROWB;
+#pragma unroll
+            for (int i = 0; i < 5; i++) {
+                const v4f Aq = *reinterpret_cast<const v4f *>(rowp + i * PXB);
+                const v4f Bq = *reinterpret_cast<const v4f *>(rowp + i * PXB + 16);
+                const v2f s2 = geo(Aq, Bq, -A.xy, -A.zw, -B.xy);
+                const float dn = fmaxf(__builtin_amdgcn_sqrtf(s2.x), 0.0f), dx = fmaxf(__builtin_amdgcn_sqrtf(s2.y), 0.0f);
+                float t = fmaf(dn, kn, neg_log2_binom(i - 2) + neg_log2_binom(j));
+                t = fmaf(dx, kx, t);
+                if (j == 1) F1[i] = t; else F2[i] = t;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 5; i++) { ppF2[i] = pF2[i]; pF2[i] = F2[i]; pF1[i] = F1[i]; }
+    }
+
+    // One iteration = one output row.  Once a non-finite normal / position has been staged (rare; the flag only ever
+    // goes from 0 to 1, and is set before the row that needs it becomes anybody's partner) the workgroup switches to a
+    // plain 24-tap loop that keeps the reference's min(1, exp(-NaN)) == 1 and shares nothing.
+    auto body = [&](int bo, int it, bool careful) {
+        __builtin_amdgcn_s_setprio(3);
+        const int y = phase + (bo << LOG2S);
+        const char *rowc = colbase + slot_of(bo) * ROWB + 2 * PXB;
+        const char *ringrow = smem + slot_of(bo) * ROWB;
+        const v4f A = *reinterpret_cast<const v4f *>(rowc);
+        const v4f B = *reinterpret_cast<const v4f *>(rowc + 16);
+        const v4f C = *reinterpret_cast<const v4f *>(rowc + 32);
+        const float *bl = blur + (it & 1) * BLUR_BUF;
+        const float m0 = bl[be_l], m1 = bl[be_c], m2 = bl[be_r];
+        const float p0 = bl[BLUR_ROW + be_l], p1 = bl[BLUR_ROW + be_c], p2 = bl[BLUR_ROW + be_r];
+        const float c0v = *reinterpret_cast<const float *>(ringrow + off_l);
+        const float c2v = *reinterpret_cast<const float *>(ringrow + off_r);
+        ColRow r0;
+        load_col(r0, bo - 2);
+        float var;
+        {   // centre variance: 3x3 gaussian with out-of-image taps dropped and renormalised (:102-118)
+            const float wr_m = (y - 1 >= 0) ? 0.25f : 0.0f, wr_p = (y + 1 < H) ? 0.25f : 0.0f;
+            const float wc_l = (x - 1 >= 0) ? 0.25f : 0.0f, wc_r = (x + 1 < W) ? 0.25f : 0.0f;
+            const float col_l = wr_m * m0 + 0.5f * c0v + wr_p * p0;
+            const float col_c = wr_m * m1 + 0.5f * C.w + wr_p * p1;
+            const float col_r = wr_m * m2 + 0.5f * c2v + wr_p * p2;
+            const float sum = wc_l * col_l + 0.5f * col_c + wc_r * col_r;
+            const float sumw = (wr_m + 0.5f + wr_p) * (wc_l + 0.5f + wc_r);
+            const float blurred = sum * __builtin_amdgcn_rcpf(sumw);
+            var = a.blur_variance ? blurred : C.w;
+        }
+        var = fmaxf(var, 0.0f);
+        const float lp = B.z;
+        const float kl = kLog2e * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(var) * sigma_c + 1e-6f);
+        const v2f c0 = v2f{-A.x, -A.y}, c1 = v2f{-A.z, -A.w}, c2 = v2f{-B.x, -B.y};      // negated centre, see geo()
+
+        // centre tap: weight exactly h = 9/64
+        constexpr float w0 = 0.140625f;
+        Acc acc;
+        acc.ww = v2f{w0, w0 * w0};
+        acc.rg = v2f{w0 * C.x, w0 * C.y};
+        acc.bv = v2f{w0 * C.z, (w0 * w0) * C.w};
+
+        if (careful) {
+            acc.rg = v2f{0.0f, 0.0f}; acc.bv = v2f{0.0f, 0.0f}; acc.ww = v2f{0.0f, 0.0f};
+#pragma unroll 1
+            for (int j = -2; j <= 2; j++) {
+                const char *rowp = colbase + slot_of(bo + j) * ROWB;
+#pragma unroll 1
+                for (int i = -2; i <= 2; i++) {
+                    const v4f Aq = *reinterpret_cast<const v4f *>(rowp + (i + 2) * PXB);
+                    const v4f Bq = *reinterpret_cast<const v4f *>(rowp + (i + 2) * PXB + 16);
+                    const v4f Cq = *reinterpret_cast<const v4f *>(rowp + (i + 2) * PXB + 32);
+                    const v2f s2 = geo(Aq, Bq, c0, c1, c2);
+                    const float dn = fmaxf(__builtin_amdgcn_sqrtf(s2.x), 0.0f), dx = fmaxf(__builtin_amdgcn_sqrtf(s2.y), 0.0f);
+                    const int ai = i < 0 ? -i : i, aj = j < 0 ? -j : j;
+                    const float nl = (ai == 0 ? 1.4150374992788437f : (ai == 1 ? 2.0f : 4.0f)) + (aj == 0 ? 1.4150374992788437f : (aj == 1 ? 2.0f : 4.0f));
+                    float e = fmaf(fabsf(Bq.z - lp), kl, nl);
+                    e = fmaf(dn, kn, e);
+                    e = fmaf(dx, kx, e);
+                    accumulate(acc, Cq, __builtin_amdgcn_exp2f(-e));
+                }
+            }
+        } else {
+        // Each row's first LDS reads are issued one row ahead (in front of the previous row's fence).
+        // ---- backward rows j = -2, -1: colour part only; t comes from the lane that owns the partner column ----
+        // tap offset io = i-2: the partner (x+io) published the pair as ITS forward term with column offset -io
+        ColRow r1;
+        load_col(r1, bo - 1);
+        {
+            float tt[5];
+            tt[0] = lane_from<-2>(ppF2[4]); tt[1] = lane_from<-1>(ppF2[3]); tt[2] = ppF2[2];
+            tt[3] = lane_from<1>(ppF2[1]);  tt[4] = lane_from<2>(ppF2[0]);
+            do_col(acc, r0, tt, lp, kl);
+        }
+        __builtin_amdgcn_s_setprio(2);
+        OwnRow r2;
+        load_own(r2, bo);
+        row_fence(acc);
+        {
+            float tt[5];
+            tt[0] = lane_from<-2>(pF1[4]); tt[1] = lane_from<-1>(pF1[3]); tt[2] = pF1[2];
+            tt[3] = lane_from<1>(pF1[1]);  tt[4] = lane_from<2>(pF1[0]);
+            do_col(acc, r1, tt, lp, kl);
+        }
+        GeoRow g1;
+#if SVGF_LANE_G1
+        load_geo(g1, bo + 1);
+#endif
+        row_fence(acc);
+#if !SVGF_LANE_G1
+        load_geo(g1, bo + 1);
+#endif
+
+        // ---- own row: the two right-hand neighbours are evaluated, the two left-hand ones arrive from lanes x-1, x-2 ----
+        {
+            float e[4], tf[2];
+#pragma unroll
+            for (int k = 0; k < 2; k++) {
+                const v2f s2 = geo(r2.A[k], r2.B[k], c0, c1, c2);
+                const float dn = __builtin_amdgcn_sqrtf(s2.x), dx = __builtin_amdgcn_sqrtf(s2.y);
+                const float t = fmaf(dn, kn, neg_log2_binom(k + 1) + neg_log2_binom(0));
+                tf[k] = fmaf(dx, kx, t);
+            }
+            const float tb1 = lane_from<-1>(tf[0]), tb2 = lane_from<-2>(tf[1]);
+            e[0] = fmaf(fabsf(r2.l[1] - lp), kl, tb2);          // io = -2
+            e[1] = fmaf(fabsf(r2.l[0] - lp), kl, tb1);          // io = -1
+            e[2] = fmaf(fabsf(r2.B[0].z - lp), kl, tf[0]);      // io = +1
+            e[3] = fmaf(fabsf(r2.B[1].z - lp), kl, tf[1]);      // io = +2
+            __builtin_amdgcn_sched_barrier(0x100);
+            float w[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) w[k] = __builtin_amdgcn_exp2f(-e[k]);
+            __builtin_amdgcn_sched_barrier(0x100);
+            accumulate(acc, r2.Cb[1], w[0]);
+            accumulate(acc, r2.Cb[0], w[1]);
+            accumulate(acc, r2.C[0], w[2]);
+            accumulate(acc, r2.C[1], w[3]);
+        }
+        __builtin_amdgcn_s_setprio(1);
+        GeoRow g2;
+#if SVGF_LANE_G2 == 0
+        load_geo(g2, bo + 2);
+#endif
+        row_fence(acc);
+
+        // ---- forward rows j = +1, +2: evaluate, use, and keep for the partners ----
+        float F1[5], F2[5];
+        do_geo(acc, g1, bo + 1, std::integral_constant<int, 1>{}, F1, c0, c1, c2, lp, kl, SVGF_LANE_G2 == 1 ? &g2 : nullptr, bo + 2);
+        __builtin_amdgcn_s_setprio(0);
+        row_fence(acc);
+#if SVGF_LANE_G2 == 2
+        load_geo(g2, bo + 2);
+#endif
+        do_geo(acc, g2, bo + 2, std::integral_constant<int, 2>{}, F2, c0, c1, c2, lp, kl, nullptr, 0);
+        row_fence(acc);
+#pragma unroll
+        for (int i = 0; i < 5; i++) { ppF2[i] = pF2[i]; pF2[i] = F2[i]; pF1[i] = F1[i]; }
+        }
+
+        if (out_lane) {
+            const float r0 = acc.rg.x, r1 = acc.rg.y, r2 = acc.bv.x, vsum = acc.bv.y, wsum = acc.ww.x, w2sum = acc.ww.y;
+            float o0, o1, o2, ov;
+            if (wsum > 1e-5f) {                                     // NaN -> false -> pass-through (:159-164)
+                const float rw = __builtin_amdgcn_rcpf(wsum);
+                o0 = r0 * rw; o1 = r1 * rw; o2 = r2 * rw;
+                ov = HASVAR ? vsum * __builtin_amdgcn_rcpf(w2sum) : 0.0f;
+            } else {
+                o0 = C.x; o1 = C.y; o2 = C.z; ov = C.w;
+            }
+            const unsigned p = (unsigned)y * (unsigned)W + (unsigned)x;
+            if (a.modulate) {                                      // last level: * albedo * ialbedo (:166-168)
+                const float *t = a.gbuf + 13u * (size_t)p;
+                o0 *= t[6] * t[9]; o1 *= t[7] * t[10]; o2 *= t[8] * t[11];
+            }
+            if (a.dst) a.dst[p] = make_float4(o0, o1, o2, ov);
+            if (a.out_rgb) { float *o = a.out_rgb + 3u * p; o[0] = o0; o[1] = o1; o[2] = o2; }
+        }
+    };
+
+    int it = 0;
+    for (int bo = b0; bo < b1; bo++, it++) {
+        body(bo, it, *nan_seen != 0);
+        __syncthreads();
+        ring_advance();
+    }
+}
+
+template <int LOG2S, bool HASVAR>
+hipError_t launch_lane_cfg(const AtrousArgs &a, hipStream_t s)
+{
+    constexpr int S = 1 << LOG2S, M = LOUT * (NWC / S) + 4, MP = (M * 12 % 64 == 0) ? M + 1 : M, BM = (BW + S - 1) / S;
+    const size_t lds = (size_t)R * S * MP * PXB + (size_t)2 * 2 * S * BM * 4 + 16;
+    static bool attr_done[64] = {};
+    int dev_id = 0;
+    (void)hipGetDevice(&dev_id);
+    if (dev_id < 0 || dev_id >= 64) dev_id = 0;
+    if (!attr_done[dev_id]) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_atrous_lane<LOG2S, HASVAR>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_done[dev_id] = true;
+    }
+    LaneGeom gm;
+    gm.n_strips = (a.W + TXO - 1) / TXO;
+    const int nb_max = (a.H + S - 1) / S;
+    static int n_cu = 0;
+    if (!n_cu) {
+        if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev_id) != hipSuccess || n_cu <= 0) n_cu = 256;
+    }
+    // segment length: one workgroup per CU (LDS-bound); the busiest XCD sets the number of rounds (see the strip kernel)
+    int best_L = nb_max;
+    long best_cost = -1;
+    for (int L = 4; L <= nb_max + 1; L++) {
+        const int segs_l = (nb_max + L - 1) / L;
+        const long blocks_xcd = (long)gm.n_strips * ((S * segs_l + 7) / 8);
+        const long rounds = (blocks_xcd + n_cu / 8 - 1) / (n_cu / 8);
+        const long cost = rounds * (L + 6);
+        if (best_cost < 0 || cost <= best_cost) { best_cost = cost; best_L = L; }
+    }
+    gm.seg_rows = best_L;
+    gm.n_segs = (nb_max + best_L - 1) / best_L;
+    gm.n_groups = S * gm.n_segs;
+    gm.kn = (float)(1.4426950408889634 / ((double)a.sigma_n + 1e-6));
+    gm.kx = (float)(1.4426950408889634 / ((double)a.sigma_x + 1e-6));
+    const int groups_pad = (gm.n_groups + 7) / 8 * 8;
+    const int nblocks = groups_pad * gm.n_strips;
+    hipLaunchKernelGGL((k_atrous_lane<LOG2S, HASVAR>), dim3(nblocks), dim3(NT), lds, s, a, gm);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+bool atrous_lane_supported(const AtrousArgs &a)
+{
+    if (a.step != 2 && a.step != 4 && a.step != 8) return false;
+    if ((long long)a.W * a.H * 16 >= (1LL << 32)) return false;
+    return true;
+}
+
+hipError_t launch_atrous_lane(const AtrousArgs &a, hipStream_t s)
+{
+    switch (a.step) {
+    case 2: return a.dst ? launch_lane_cfg<1, true>(a, s) : launch_lane_cfg<1, false>(a, s);
+    case 4: return a.dst ? launch_lane_cfg<2, true>(a, s) : launch_lane_cfg<2, false>(a, s);
+    case 8: return a.dst ? launch_lane_cfg<3, true>(a, s) : launch_lane_cfg<3, false>(a, s);
+    default: return hipErrorInvalidValue;
+    }
+}

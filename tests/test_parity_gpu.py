@@ -44,7 +44,7 @@ def native_loaded(pkg):
     assert lib.svgf_version() > 0
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4])
 @pytest.mark.parametrize("name", CASES)
 def test_hip_matches_reference_goldens(pkg, name, variant):
     z, runs = load_golden(name)
@@ -53,7 +53,7 @@ def test_hip_matches_reference_goldens(pkg, name, variant):
         nl = int(z[f"call_params_{tag}"][0][8])
         if variant == 2 and nl > 5:
             continue                                   # steps 64,128 are served by the gather kernel
-        if variant == 3 and (nl > 5 or name.startswith("temporal_")):
+        if variant in (3, 4) and (nl > 5 or name.startswith("temporal_")):
             continue                                   # 3 = experimental shared-weight kernel (a-trous steps 2-8 only)
         e = Engine(pkg, W, H, variant)
         got = replay(pkg, e, z, tag)
