@@ -199,7 +199,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, profiles/pmc_traffic.json (FETCH x2 per MI355X_MICROARCH.md)",
-                         "kernel": "k_atrous_strip (one a-trous level)", "bytes_per_launch": ATROUS_BYTES_PER_PIXEL * W * H,
+                         "kernel": "one a-trous level: k_atrous_lane (steps 2-8), k_atrous_strip (steps 16-32); mean over the 5 launches of a frame", "bytes_per_launch": ATROUS_BYTES_PER_PIXEL * W * H,
                          "mean_launch_us": round(a_ms * 1e3, 2), "launches_timed": len(atrous_ms),
                          "note": "timed-region launches include levels that run beside the next frame's temporal pass "
                                  "(cross-frame overlap); 'isolated' is the same kernel with the GPU to itself",
