@@ -55,6 +55,8 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 struct LaneGeom {
     int n_strips, n_segs, seg_rows, n_groups;
     float kn, kx;
+    unsigned long long *dbg;   // tuning only (-DSVGF_LANE_TIMELINE + SVGF_LANE_DBG=<block>): s_memtime stamps of one workgroup
+    int dbg_block;
 };
 
 struct Px {
@@ -124,6 +126,15 @@ __global__ __launch_bounds__(NT) void k_atrous_lane(AtrousArgs a, LaneGeom gm)
     if (tid == 0) *nan_seen = 0;
     float sigma_c = a.sigma_c;
     asm volatile("" : "+s"(sigma_c));
+    int dbg_it = 0;
+    auto stamp = [&](int id) {
+#ifdef SVGF_LANE_TIMELINE
+        if (gm.dbg && bid == gm.dbg_block && (tid & 63) == 0 && dbg_it < 16)
+            gm.dbg[((tid >> 6) * 16 + dbg_it) * 8 + id] = __builtin_amdgcn_s_memtime();
+#else
+        (void)id; (void)dbg_it;
+#endif
+    };
 
     // ring slot of lattice row br: `ring_base` is the slot of row ring_b - 2 (wave-uniform, advanced once per iteration)
     int ring_base = 0, ring_b = b0;
@@ -290,11 +301,14 @@ __global__ __launch_bounds__(NT) void k_atrous_lane(AtrousArgs a, LaneGeom gm)
         // ================================ loader waves (as in the strip kernel) ================================
         __builtin_amdgcn_s_setprio(2);
         int it = 0;
-        for (int bo = b0; bo < b1; bo++, it++) {
+        for (int bo = b0; bo < b1; bo++, it++, dbg_it++) {
+            stamp(0);
             if (it == 0 && lgroup >= 1) loader_issue(lgroup);
             if ((it + 1) % kLoaderGroups == lgroup) loader_commit(it + 1);
             else if (it % kLoaderGroups == lgroup) loader_issue(it + kLoaderGroups);
+            stamp(5);
             __syncthreads();
+            stamp(6);
             ring_advance();
         }
         return;
@@ -302,6 +316,7 @@ __global__ __launch_bounds__(NT) void k_atrous_lane(AtrousArgs a, LaneGeom gm)
 
     // ================================ compute waves ================================
     const int lane = tid & 63, wv = tid >> 6;
+    const bool flip = (wv >= NWC / 2);              // stage order of this wave, see body()
     const int xph = wv / WPP;                       // x-phase of this wave
     const int mcol = (wv % WPP) * LOUT + lane;      // lattice column inside the phase, 0 .. M-1
     const int xi = xph + S * mcol;                  // staged pixel column
@@ -326,9 +341,19 @@ __global__ __launch_bounds__(NT) void k_atrous_lane(AtrousArgs a, LaneGeom gm)
     };
 
     // forward terms kept across iterations: index 0..4 <-> partner column offset -2..+2
-    float pF1[5], pF2[5], ppF2[5];
+    // The queue holds the terms ALREADY MOVED to the lane that will consume them, indexed by the consumer's tap
+    // (k = 0..4 <-> tap column offset k-2): the consumer's partner x+(k-2) published the pair as its forward offset
+    // -(k-2), i.e. as its element 4-k.  The shifts are issued where the terms are produced (the throughput-bound forward
+    // rows) so that the backward rows, which open the next iterations, do not wait on two dependent DPP moves.
+    float pF1[5], pF2[5], ppF2[5];     // for the consumer's row -1 (next iteration), row -2 (in two iterations), row -2 (next)
 #pragma unroll
     for (int i = 0; i < 5; i++) { pF1[i] = 0.0f; pF2[i] = 0.0f; ppF2[i] = 0.0f; }
+    auto publish = [&](const float (&F1)[5], const float (&F2)[5]) {
+#pragma unroll
+        for (int i = 0; i < 5; i++) ppF2[i] = pF2[i];
+        pF1[0] = lane_from<-2>(F1[4]); pF1[1] = lane_from<-1>(F1[3]); pF1[2] = F1[2]; pF1[3] = lane_from<1>(F1[1]); pF1[4] = lane_from<2>(F1[0]);
+        pF2[0] = lane_from<-2>(F2[4]); pF2[1] = lane_from<-1>(F2[3]); pF2[2] = F2[2]; pF2[3] = lane_from<1>(F2[1]); pF2[4] = lane_from<2>(F2[0]);
+    };
 
     // forward rows (j = +1, +2) of the centre in lattice row br: 10 evaluations -> F1, F2 (+ optional taps)
     struct Acc { v2f rg, bv, ww; };
@@ -453,14 +478,14 @@ __global__ __launch_bounds__(NT) void k_atrous_lane(AtrousArgs a, LaneGeom gm)
                 if (j == 1) F1[i] = t; else F2[i] = t;
             }
         }
-#pragma unroll
-        for (int i = 0; i < 5; i++) { ppF2[i] = pF2[i]; pF2[i] = F2[i]; pF1[i] = F1[i]; }
+        publish(F1, F2);
     }
 
     // One iteration = one output row.  Once a non-finite normal / position has been staged (rare; the flag only ever
     // goes from 0 to 1, and is set before the row that needs it becomes anybody's partner) the workgroup switches to a
     // plain 24-tap loop that keeps the reference's min(1, exp(-NaN)) == 1 and shares nothing.
     auto body = [&](int bo, int it, bool careful) {
+        stamp(0);
         __builtin_amdgcn_s_setprio(3);
         const int y = phase + (bo << LOG2S);
         const char *rowc = colbase + slot_of(bo) * ROWB + 2 * PXB;
@@ -474,7 +499,8 @@ __global__ __launch_bounds__(NT) void k_atrous_lane(AtrousArgs a, LaneGeom gm)
         const float c0v = *reinterpret_cast<const float *>(ringrow + off_l);
         const float c2v = *reinterpret_cast<const float *>(ringrow + off_r);
         ColRow r0;
-        load_col(r0, bo - 2);
+        GeoRow g1;
+        if (flip) load_geo(g1, bo + 1); else load_col(r0, bo - 2);       // the first tap row of this wave's stage order
         float var;
         {   // centre variance: 3x3 gaussian with out-of-image taps dropped and renormalised (:102-118)
             const float wr_m = (y - 1 >= 0) ? 0.25f : 0.0f, wr_p = (y + 1 < H) ? 0.25f : 0.0f;
@@ -492,6 +518,7 @@ __global__ __launch_bounds__(NT) void k_atrous_lane(AtrousArgs a, LaneGeom gm)
         const float kl = kLog2e * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(var) * sigma_c + 1e-6f);
         const v2f c0 = v2f{-A.x, -A.y}, c1 = v2f{-A.z, -A.w}, c2 = v2f{-B.x, -B.y};      // negated centre, see geo()
 
+        stamp(1);
         // centre tap: weight exactly h = 9/64
         constexpr float w0 = 0.140625f;
         Acc acc;
@@ -521,37 +548,8 @@ __global__ __launch_bounds__(NT) void k_atrous_lane(AtrousArgs a, LaneGeom gm)
             }
         } else {
         // Each row's first LDS reads are issued one row ahead (in front of the previous row's fence).
-        // ---- backward rows j = -2, -1: colour part only; t comes from the lane that owns the partner column ----
-        // tap offset io = i-2: the partner (x+io) published the pair as ITS forward term with column offset -io
-        ColRow r1;
-        load_col(r1, bo - 1);
-        {
-            float tt[5];
-            tt[0] = lane_from<-2>(ppF2[4]); tt[1] = lane_from<-1>(ppF2[3]); tt[2] = ppF2[2];
-            tt[3] = lane_from<1>(ppF2[1]);  tt[4] = lane_from<2>(ppF2[0]);
-            do_col(acc, r0, tt, lp, kl);
-        }
-        __builtin_amdgcn_s_setprio(2);
-        OwnRow r2;
-        load_own(r2, bo);
-        row_fence(acc);
-        {
-            float tt[5];
-            tt[0] = lane_from<-2>(pF1[4]); tt[1] = lane_from<-1>(pF1[3]); tt[2] = pF1[2];
-            tt[3] = lane_from<1>(pF1[1]);  tt[4] = lane_from<2>(pF1[0]);
-            do_col(acc, r1, tt, lp, kl);
-        }
-        GeoRow g1;
-#if SVGF_LANE_G1
-        load_geo(g1, bo + 1);
-#endif
-        row_fence(acc);
-#if !SVGF_LANE_G1
-        load_geo(g1, bo + 1);
-#endif
-
-        // ---- own row: the two right-hand neighbours are evaluated, the two left-hand ones arrive from lanes x-1, x-2 ----
-        {
+        // own row: the two right-hand neighbours are evaluated, the two left-hand ones arrive from lanes x-1, x-2
+        auto do_own = [&](const OwnRow &r2) {
             float e[4], tf[2];
 #pragma unroll
             for (int k = 0; k < 2; k++) {
@@ -574,28 +572,65 @@ __global__ __launch_bounds__(NT) void k_atrous_lane(AtrousArgs a, LaneGeom gm)
             accumulate(acc, r2.Cb[0], w[1]);
             accumulate(acc, r2.C[0], w[2]);
             accumulate(acc, r2.C[1], w[3]);
-        }
-        __builtin_amdgcn_s_setprio(1);
-        GeoRow g2;
-#if SVGF_LANE_G2 == 0
-        load_geo(g2, bo + 2);
-#endif
-        row_fence(acc);
-
-        // ---- forward rows j = +1, +2: evaluate, use, and keep for the partners ----
+        };
         float F1[5], F2[5];
-        do_geo(acc, g1, bo + 1, std::integral_constant<int, 1>{}, F1, c0, c1, c2, lp, kl, SVGF_LANE_G2 == 1 ? &g2 : nullptr, bo + 2);
-        __builtin_amdgcn_s_setprio(0);
-        row_fence(acc);
-#if SVGF_LANE_G2 == 2
-        load_geo(g2, bo + 2);
-#endif
-        do_geo(acc, g2, bo + 2, std::integral_constant<int, 2>{}, F2, c0, c1, c2, lp, kl, nullptr, 0);
-        row_fence(acc);
-#pragma unroll
-        for (int i = 0; i < 5; i++) { ppF2[i] = pF2[i]; pF2[i] = F2[i]; pF1[i] = F1[i]; }
+        if (!flip) {
+            // ---- stage order A (waves 0-3): backward rows, own row, forward rows ----
+            // backward rows: colour part only; t comes from the queue (already moved to this lane by publish())
+            ColRow r1;
+            load_col(r1, bo - 1);
+            do_col(acc, r0, ppF2, lp, kl);
+            __builtin_amdgcn_s_setprio(2);
+            OwnRow r2;
+            load_own(r2, bo);
+            row_fence(acc);
+            do_col(acc, r1, pF1, lp, kl);
+            load_geo(g1, bo + 1);
+            row_fence(acc);
+            stamp(2);
+            do_own(r2);
+            __builtin_amdgcn_s_setprio(1);
+            stamp(3);
+            row_fence(acc);
+            // forward rows: evaluate, use, and keep for the partners
+            do_geo(acc, g1, bo + 1, std::integral_constant<int, 1>{}, F1, c0, c1, c2, lp, kl, nullptr, 0);
+            __builtin_amdgcn_s_setprio(0);
+            row_fence(acc);
+            GeoRow g2;
+            load_geo(g2, bo + 2);
+            do_geo(acc, g2, bo + 2, std::integral_constant<int, 2>{}, F2, c0, c1, c2, lp, kl, nullptr, 0);
+            row_fence(acc);
+        } else {
+            // ---- stage order B (waves 4-7, which share their SIMDs with waves 0-3): forward rows, own row, backward
+            //      rows.  The forward rows are VALU-heavy, the backward rows LDS-heavy: with the two waves of a SIMD in
+            //      opposite orders the two kinds of work overlap instead of queueing up behind the same pipe. ----
+            do_geo(acc, g1, bo + 1, std::integral_constant<int, 1>{}, F1, c0, c1, c2, lp, kl, nullptr, 0);
+            __builtin_amdgcn_s_setprio(2);
+            row_fence(acc);
+            GeoRow g2;
+            load_geo(g2, bo + 2);
+            do_geo(acc, g2, bo + 2, std::integral_constant<int, 2>{}, F2, c0, c1, c2, lp, kl, nullptr, 0);
+            OwnRow r2;
+            load_own(r2, bo);
+            row_fence(acc);
+            stamp(2);
+            load_col(r0, bo - 2);
+            do_own(r2);
+            __builtin_amdgcn_s_setprio(1);
+            stamp(3);
+            row_fence(acc);
+            ColRow r1;
+            load_col(r1, bo - 1);
+            do_col(acc, r0, ppF2, lp, kl);
+            __builtin_amdgcn_s_setprio(0);
+            row_fence(acc);
+            do_col(acc, r1, pF1, lp, kl);
+            row_fence(acc);
+        }
+        publish(F1, F2);
         }
 
+        stamp(4);
         if (out_lane) {
             const float r0 = acc.rg.x, r1 = acc.rg.y, r2 = acc.bv.x, vsum = acc.bv.y, wsum = acc.ww.x, w2sum = acc.ww.y;
             float o0, o1, o2, ov;
@@ -619,8 +654,11 @@ __global__ __launch_bounds__(NT) void k_atrous_lane(AtrousArgs a, LaneGeom gm)
     int it = 0;
     for (int bo = b0; bo < b1; bo++, it++) {
         body(bo, it, *nan_seen != 0);
+        stamp(5);
         __syncthreads();
+        stamp(6);
         ring_advance();
+        dbg_it++;
     }
 }
 
@@ -663,7 +701,39 @@ hipError_t launch_lane_cfg(const AtrousArgs &a, hipStream_t s)
     gm.kx = (float)(1.4426950408889634 / ((double)a.sigma_x + 1e-6));
     const int groups_pad = (gm.n_groups + 7) / 8 * 8;
     const int nblocks = groups_pad * gm.n_strips;
+    gm.dbg = nullptr; gm.dbg_block = 0;
+#ifdef SVGF_LANE_TIMELINE
+    static unsigned long long *dbg_buf = nullptr;
+    const char *dbg_env = getenv("SVGF_LANE_DBG");
+    if (dbg_env) {
+        if (!dbg_buf) (void)hipMalloc((void **)&dbg_buf, 16 * 16 * 8 * sizeof(unsigned long long));
+        (void)hipMemsetAsync(dbg_buf, 0, 16 * 16 * 8 * sizeof(unsigned long long), s);
+        gm.dbg = dbg_buf; gm.dbg_block = atoi(dbg_env);
+    }
+#endif
     hipLaunchKernelGGL((k_atrous_lane<LOG2S, HASVAR>), dim3(nblocks), dim3(NT), lds, s, a, gm);
+#ifdef SVGF_LANE_TIMELINE
+    if (dbg_env) {
+        static int skip = getenv("SVGF_LANE_DBG_SKIP") ? atoi(getenv("SVGF_LANE_DBG_SKIP")) : 0, prints = 0;
+        (void)hipStreamSynchronize(s);
+        unsigned long long h[16 * 16 * 8];
+        (void)hipMemcpy(h, dbg_buf, sizeof(h), hipMemcpyDeviceToHost);
+        if (skip > 0) skip--;
+        else if (prints++ < 4) {
+            fprintf(stderr, "[lane dbg] S=%d blocks=%d segs=%d seg_rows=%d lds=%zu\n", S, nblocks, gm.n_segs, gm.seg_rows, lds);
+            const int show[4] = { 0, NWC - 1, NWC, NWC + 3 };
+            for (int si = 0; si < 4; si++) {
+                const int w = show[si];
+                for (int it = 0; it < 8 && h[(w * 16 + it) * 8]; it++) {
+                    unsigned long long *t = &h[(w * 16 + it) * 8];
+                    if (w >= NWC) fprintf(stderr, "  loader %2d it %2d: t0=%6llu work %6llu barrier %5llu\n", w, it, t[0] - h[0], t[5] - t[0], t[6] - t[5]);
+                    else fprintf(stderr, "  wave %2d it %2d: t0=%6llu centre %5llu back rows %5llu own %5llu fwd rows %5llu out %5llu barrier %5llu\n", w, it,
+                                 t[0] - h[0], t[1] - t[0], t[2] - t[1], t[3] - t[2], t[4] - t[3], t[5] - t[4], t[6] - t[5]);
+                }
+            }
+        }
+    }
+#endif
     return hipGetLastError();
 }
 
