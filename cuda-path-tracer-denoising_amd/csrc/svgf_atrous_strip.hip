@@ -48,9 +48,6 @@ constexpr float kLog2e = 1.44269504088896340736f;
 #ifndef SVGF_LOADER_DIV
 #define SVGF_LOADER_DIV 2
 #endif
-#ifndef SVGF_STRIP_ATTR
-#define SVGF_STRIP_ATTR
-#endif
 // Wave priorities (s_setprio).  The SIMD arbiter serves the oldest ready wave first, so of the two compute waves that
 // share a SIMD the older one used to finish its iteration ~2000 cycles early and idle at the barrier while the younger
 // ran alone, unable to hide its own latencies (profiles/r01_strip_phase_timeline_v3.log: taps 4300 vs 5650 cycles).
@@ -151,7 +148,7 @@ __device__ __forceinline__ constexpr float neg_log2_binom(int i)
 // HASVAR = false: the level's filtered variance is not needed (last level, no colour-history copy): the two variance
 // accumulators (sum w^2, sum w^2 var) and the w*w product drop out of every tap.
 template <int LOG2S, int TX, int ROWS, bool HASVAR>
-__global__ __launch_bounds__(TX * ROWS + loader_threads(TX, ROWS)) SVGF_STRIP_ATTR void k_atrous_strip(AtrousArgs a, StripGeom gm)
+__global__ __launch_bounds__(TX * ROWS + loader_threads(TX, ROWS)) void k_atrous_strip(AtrousArgs a, StripGeom gm)
 {
     constexpr int S = 1 << LOG2S;
     constexpr int RW = TX + 4 * S;          // staged pixels per lattice row
@@ -546,12 +543,8 @@ __global__ __launch_bounds__(TX * ROWS + loader_threads(TX, ROWS)) SVGF_STRIP_AT
 #pragma unroll
                     for (int i = 0; i < 5; i++) {
                         if (i == 2 && j == 0) continue;
-#ifdef SVGF_HACK_NOSQRT
-                        dn[i] = s2[i].x; dx[i] = s2[i].y;
-#else
                         dn[i] = __builtin_amdgcn_sqrtf(s2[i].x);
                         dx[i] = __builtin_amdgcn_sqrtf(s2[i].y);
-#endif
                     }
                     __builtin_amdgcn_sched_barrier(0x100);
                     float e[5];
@@ -566,11 +559,7 @@ __global__ __launch_bounds__(TX * ROWS + loader_threads(TX, ROWS)) SVGF_STRIP_AT
                     float w[5];
 #pragma unroll
                     for (int i = 0; i < 5; i++)
-#ifdef SVGF_HACK_NOEXP
-                        if (!(i == 2 && j == 0)) w[i] = -e[i];
-#else
                         if (!(i == 2 && j == 0)) w[i] = __builtin_amdgcn_exp2f(-e[i]);
-#endif
                     __builtin_amdgcn_sched_barrier(0x100);
 #pragma unroll
                     for (int i = 0; i < 5; i++) {
@@ -593,16 +582,8 @@ __global__ __launch_bounds__(TX * ROWS + loader_threads(TX, ROWS)) SVGF_STRIP_AT
                         for (int i = 0; i < 5; i++) { Ac[i] = An[i]; Bc[i] = Bn[i]; }
                     }
                     // the wave that is ahead lowers its own priority, so the two compute waves of a SIMD finish together
-#if SVGF_PROGRESS_PRIO == 1
+#if SVGF_PROGRESS_PRIO
                     if (j == -1) __builtin_amdgcn_s_setprio(2);
-                    if (j == 0) __builtin_amdgcn_s_setprio(1);
-                    if (j == 1) __builtin_amdgcn_s_setprio(0);
-#elif SVGF_PROGRESS_PRIO == 2
-                    if (j == -2) __builtin_amdgcn_s_setprio(2);
-                    if (j == -1) __builtin_amdgcn_s_setprio(1);
-                    if (j == 0) __builtin_amdgcn_s_setprio(0);
-#elif SVGF_PROGRESS_PRIO == 3
-                    if (j == -2) __builtin_amdgcn_s_setprio(2);
                     if (j == 0) __builtin_amdgcn_s_setprio(1);
                     if (j == 1) __builtin_amdgcn_s_setprio(0);
 #endif
