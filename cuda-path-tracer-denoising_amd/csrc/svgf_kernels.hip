@@ -117,7 +117,9 @@ __global__ __launch_bounds__(BLOCK) void k_temporal(TemporalArgs a)
             float cnt = 0.0f;
             for (int yy = -1; yy <= 1; yy++)
                 for (int xx = -1; xx <= 1; xx++) {
-                    const int q = reproj_valid(a, fx + (float)xx, fy + (float)yy, gid, nx, ny, nz);
+                    // the four taps with xx, yy in {0, 1} are the bilinear taps tested above: same arguments, same answer
+                    const int q = (xx >= 0 && yy >= 0) ? q4[xx + 2 * yy]
+                                                       : reproj_valid(a, fx + (float)xx, fy + (float)yy, gid, nx, ny, nz);
                     if (q >= 0) {
                         const float4 ch = a.cv_hist[q];
                         const float2 mh = a.mom_hist[q];
