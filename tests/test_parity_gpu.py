@@ -236,3 +236,26 @@ def test_error_codes(pkg):
     lib = pkg.load_library()
     h = ctypes.c_void_p()
     assert lib.svgf_create(99, 8, 8, ctypes.byref(h)) == -2
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("env", [{"SVGF_STRIP_ROWS": "3"}, {"SVGF_STRIP_TX": "128"}, {"SVGF_STRIP_ROWS": "1"},
+                                 {"SVGF_STRIP_TX": "128", "SVGF_STRIP_ROWS": "1"}])
+def test_strip_kernel_tuning_configurations_stay_correct(pkg, env, monkeypatch):
+    """The strip kernel's alternative shapes (12 compute waves, 128-column strips, one row per iteration) are only
+    reachable through tuning environment variables; they must keep giving the reference's result."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    for name in ("atrous_rand37x23_n5", "atrous_synth128x72_n5", "atrous_nanpos40x32_n2", "full_static96x54"):
+        if name not in CASES:
+            continue
+        z, runs = load_golden(name)
+        W, H = int(z["W"]), int(z["H"])
+        for tag in runs:
+            if int(z[f"call_params_{tag}"][0][8]) > 5:
+                continue
+            e = Engine(pkg, W, H, 2)
+            got = replay(pkg, e, z, tag)
+            e.free()
+            err = relerr(got, z[f"ref_nofma_out_{tag}"])
+            assert err.max() <= TOL_STRIP, f"{env} {name}:{tag} max rel {err.max():.3e}"
