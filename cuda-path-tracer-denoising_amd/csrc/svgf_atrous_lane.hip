@@ -580,21 +580,20 @@ __global__ __launch_bounds__(NT) void k_atrous_lane(AtrousArgs a, LaneGeom gm)
             ColRow r1;
             load_col(r1, bo - 1);
             do_col(acc, r0, ppF2, lp, kl);
-            __builtin_amdgcn_s_setprio(2);
             OwnRow r2;
             load_own(r2, bo);
             row_fence(acc);
             do_col(acc, r1, pF1, lp, kl);
+            __builtin_amdgcn_s_setprio(2);                  // ~1/4 of the row's work done
             load_geo(g1, bo + 1);
             row_fence(acc);
             stamp(2);
             do_own(r2);
-            __builtin_amdgcn_s_setprio(1);
             stamp(3);
             row_fence(acc);
             // forward rows: evaluate, use, and keep for the partners
             do_geo(acc, g1, bo + 1, std::integral_constant<int, 1>{}, F1, c0, c1, c2, lp, kl, nullptr, 0);
-            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_s_setprio(1);                  // ~2/3
             row_fence(acc);
             GeoRow g2;
             load_geo(g2, bo + 2);
@@ -605,24 +604,24 @@ __global__ __launch_bounds__(NT) void k_atrous_lane(AtrousArgs a, LaneGeom gm)
             //      rows.  The forward rows are VALU-heavy, the backward rows LDS-heavy: with the two waves of a SIMD in
             //      opposite orders the two kinds of work overlap instead of queueing up behind the same pipe. ----
             do_geo(acc, g1, bo + 1, std::integral_constant<int, 1>{}, F1, c0, c1, c2, lp, kl, nullptr, 0);
-            __builtin_amdgcn_s_setprio(2);
+            __builtin_amdgcn_s_setprio(2);                  // ~1/3
             row_fence(acc);
             GeoRow g2;
             load_geo(g2, bo + 2);
             do_geo(acc, g2, bo + 2, std::integral_constant<int, 2>{}, F2, c0, c1, c2, lp, kl, nullptr, 0);
+            __builtin_amdgcn_s_setprio(1);                  // ~2/3
             OwnRow r2;
             load_own(r2, bo);
             row_fence(acc);
             stamp(2);
             load_col(r0, bo - 2);
             do_own(r2);
-            __builtin_amdgcn_s_setprio(1);
+            __builtin_amdgcn_s_setprio(0);                  // ~3/4
             stamp(3);
             row_fence(acc);
             ColRow r1;
             load_col(r1, bo - 1);
             do_col(acc, r0, ppF2, lp, kl);
-            __builtin_amdgcn_s_setprio(0);
             row_fence(acc);
             do_col(acc, r1, pF1, lp, kl);
             row_fence(acc);
