@@ -9,5 +9,5 @@ Directory layout:
 The directory name contains '-', so it is loaded through `__graft_entry__.load_package()` under the module
 name `cuda_path_tracer_denoising_amd`.
 """
-from . import binding, build, farm, synth  # noqa: F401
+from . import binding, build, farm, scene, synth  # noqa: F401
 from .binding import Denoiser, SvgfCamera, SvgfParams, SvgfError, load_library, reference_defaults  # noqa: F401

@@ -183,6 +183,25 @@ int svgf_synth_camera(int frame, int moving, int width, int height, SvgfCamera *
 int svgf_synth_render(int device, void *out_rgb_dev, void *out_gbuffer_dev, int width, int height,
                       const SvgfCamera *cam, const SvgfSynthParams *sp, void *stream);
 
+/* ---- "next" row f3: scene-driven producer --------------------------------------------------------
+ * The reference's scenes are transformed unit cubes / spheres (src/scene.cpp:47-117, src/intersections.h:50,104; meshes
+ * belong to the out-of-scope path tracer).  The host side (scene.py: the MATERIAL / OBJECT / CAMERA text format) builds
+ * these records; svgf_scene_render casts the primary rays against them and writes colour + G-buffer like
+ * svgf_synth_render does for its built-in scene.  geomId = index into `geoms`.  `geoms` and `light` are host memory. */
+#define SVGF_SCENE_MAX_GEOMS 64
+typedef struct SvgfSceneGeom {
+    int   type;              /* 0 cube [-0.5,0.5]^3, 1 sphere r = 0.5 (object space) */
+    int   material;          /* material id of the scene file (informational) */
+    float albedo[3];         /* material RGB */
+    float emittance;         /* > 0: emitter */
+    float xf[12];            /* object -> world, 3x4 row-major: T * Rx * Ry * Rz * S (src/utilities.cpp:65-72) */
+    float inv[12];           /* world -> object */
+    float invT[9];           /* transpose of inv's 3x3 block (normals of curved primitives) */
+} SvgfSceneGeom;
+int svgf_scene_render(int device, void *out_rgb_dev, void *out_gbuffer_dev, int width, int height,
+                      const SvgfCamera *cam, const SvgfSynthParams *sp, const SvgfSceneGeom *geoms, int n_geoms,
+                      const float light[3], void *stream);
+
 /* ---- "next" row f2: the step right after denoise() ------------------------------------------------
  * svgf_display_pack: reference sendTwoImagesToPBO (src/pathtrace.cu:45-77, launched at :446): `left` (the 1-spp
  *   image) and `right` (the denoised image), both packed rgb floats in device memory, side by side into a

@@ -18,6 +18,7 @@ def main():
     ap.add_argument("--size", default="640x360")
     ap.add_argument("--frames", type=int, default=16)
     ap.add_argument("--moving", action="store_true")
+    ap.add_argument("--scene", default=None, help="scene text file (reference format): primitives rendered by svgf_scene_render")
     ap.add_argument("--exact-reprojection", action="store_true", help="SvgfParams::reproj_scale = (tan(fovy) W/H, tan(fovy))")
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "side_by_side.png"))
     a = ap.parse_args()
@@ -33,9 +34,17 @@ def main():
     gb = torch.empty((H * W * 52,), dtype=torch.uint8, device="cuda")
     out = torch.empty((H, W, 3), dtype=torch.float32, device="cuda")
     s = torch.cuda.current_stream()
+    scene = geoms = None
+    if a.scene:
+        scene = pkg.scene.parse_scene(open(a.scene).read())
+        geoms = pkg.scene.geom_array(scene)
     for f in range(a.frames):
-        cam = pkg.synth.camera_for_frame(f, a.moving)
-        pkg.binding.synth_render(rgb, gb, W, H, cam, f, seed=1, stream=s)
+        if scene is not None:
+            cam = pkg.scene.camera_for_frame(scene, f, a.moving)
+            pkg.binding.scene_render(rgb, gb, W, H, cam, geoms, f, seed=1, stream=s)
+        else:
+            cam = pkg.synth.camera_for_frame(f, a.moving)
+            pkg.binding.synth_render(rgb, gb, W, H, cam, f, seed=1, stream=s)
         den.denoise(out, rgb, gb, cam, params, stream=s)
     torch.cuda.synchronize()
     side = np.concatenate([rgb.cpu().numpy(), out.cpu().numpy()], axis=1)
