@@ -66,3 +66,19 @@ def test_two_rank_farm():
                 out = o.denoise(*fr, p)
             o.free()
             assert np.isclose(float(out.sum()), checks[s], rtol=0, atol=0)
+
+
+def test_bench_refuses_to_run_without_a_gpu():
+    """bench.py measures the HIP path only: on a host without a GPU it must stop with a clear message, not fall back."""
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.is_available():
+        import pytest
+        pytest.skip("GPU present")
+    from conftest import ROOT
+    import os
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert r.returncode != 0
+    assert "needs a GPU" in (r.stderr + r.stdout)
