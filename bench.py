@@ -184,9 +184,9 @@ def main():
         iso_us = float(np.mean(iso_atrous_ms)) * 1e3
         iso_gbs = ATROUS_BYTES_PER_PIXEL * W * H / (iso_us * 1e-6) / 1e9
         line = {
-            "metric": ("SVGF Mpixels/s (one non-temporal level, BASELINE configs[0]) at 800x800; a-trous HBM GB/s vs roofline" if a.config == "config1"
-                       else "SVGF Mpixels/s (full pipeline) at 4K; a-trous HBM GB/s vs roofline" if a.config.startswith("4k")
-                       else "SVGF Mpixels/s (full pipeline) at 1080p; a-trous HBM GB/s vs roofline"),
+            "metric": ("SVGF Mpixels/s (one non-temporal level, BASELINE configs[0]) at 800x800; \u00e0-trous HBM GB/s vs roofline" if a.config == "config1"
+                       else "SVGF Mpixels/s (full pipeline) at 4K; \u00e0-trous HBM GB/s vs roofline" if a.config.startswith("4k")
+                       else "SVGF Mpixels/s (full pipeline) at 1080p; \u00e0-trous HBM GB/s vs roofline"),
             "value": round(value, 2), "unit": "Mpixels/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(dt / a.steps * 1e3, 5), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
