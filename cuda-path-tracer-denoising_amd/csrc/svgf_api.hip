@@ -451,9 +451,10 @@ extern "C" int svgf_denoise(svgf_ctx *c, void *out_rgb_dev, const void *in_rgb_d
             a.sigma_c = p->sigma_l; a.sigma_n = p->sigma_n; a.sigma_x = p->sigma_x;
             a.blur_variance = p->blur_variance ? 1 : 0;
             a.modulate = (last && p->sepcolor && p->addcolor) ? 1 : 0;
-            bool strip = false;
+            bool strip = false, lattice = false;
             if (p->kernel_variant != 1) {
                 strip = atrous_strip_supported(a);
+                lattice = !strip && p->kernel_variant != 2 && atrous_lattice_supported(a);     // steps 64, 128, ...
                 if (!strip && p->kernel_variant == 2) {
                     snprintf(c->err, sizeof(c->err), "svgf_denoise: strip kernel does not support %dx%d step %d", c->W, c->H, a.step);
                     return SVGF_ERR_UNSUPPORTED;
@@ -462,8 +463,9 @@ extern "C" int svgf_denoise(svgf_ctx *c, void *out_rgb_dev, const void *in_rgb_d
             if (strip && p->kernel_variant == 3 && atrous_share_supported(a)) LAUNCH(SVGF_KERNEL_ATROUS, launch_atrous_share(a, s));
             else if (strip && atrous_lane_supported(a) && (p->kernel_variant == 4 || (p->kernel_variant == 0 && lane_pays(c->W))))
                 LAUNCH(SVGF_KERNEL_ATROUS, launch_atrous_lane(a, s));      // steps 2, 4, 8: symmetric terms evaluated once
-            else if (strip) LAUNCH(SVGF_KERNEL_ATROUS, launch_atrous_strip(a, s));
-            else            LAUNCH(SVGF_KERNEL_ATROUS, launch_atrous_gather(a, s));
+            else if (strip)   LAUNCH(SVGF_KERNEL_ATROUS, launch_atrous_strip(a, s));
+            else if (lattice) LAUNCH(SVGF_KERNEL_ATROUS, launch_atrous_lattice(a, s));
+            else              LAUNCH(SVGF_KERNEL_ATROUS, launch_atrous_gather(a, s));
             if (hist_final && dst >= 0) c->inflight_mask |= 1u << dst;   // written after the history is final
             if (keep) {
                 c->hist = dst;

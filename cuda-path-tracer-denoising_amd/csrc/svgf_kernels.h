@@ -52,6 +52,8 @@ hipError_t launch_atrous_share(const AtrousArgs &a, hipStream_t s);    // strip 
 bool       atrous_share_supported(const AtrousArgs &a);
 hipError_t launch_atrous_lane(const AtrousArgs &a, hipStream_t s);     // lane-marching kernel, symmetric terms shared by DPP (steps 2,4,8)
 bool       atrous_lane_supported(const AtrousArgs &a);
+hipError_t launch_atrous_lattice(const AtrousArgs &a, hipStream_t s);  // lattice sub-images in LDS (steps >= 64)
+bool       atrous_lattice_supported(const AtrousArgs &a);
 // out = float(value)/scale broadcast to rgb (reference DebugView :331-340)
 hipError_t launch_debug_hlen(const int *hlen, float *out_rgb, int n, float scale, hipStream_t s);
 hipError_t launch_debug_var(const float4 *cv, float *out_rgb, int n, float scale, hipStream_t s);

@@ -75,10 +75,11 @@ typedef struct SvgfParams {
     int   addcolor;           /* ui_addcolor         (0)    */
     int   right_view_option;  /* ui_right_view_option (0): 0 image, 1 history length, 2 variance */
     /* --- extensions; 0 == reference behaviour --- */
-    int   kernel_variant;     /* 0 auto (lane-marching kernel for steps 2-8, LDS strip kernel for steps 16-32, gather
-                                 beyond), 1 strict gather kernel, 2 LDS strip kernel for every step 2-32 (error if a step
-                                 is unsupported), 3 experimental: two-pass shared-weight kernel for steps 2-8 (correct,
-                                 slower), 4 lane-marching kernel for steps 2-8 + strip (what auto selects) */
+    int   kernel_variant;     /* 0 auto (lane-marching kernel for steps 2-8, LDS strip kernel for steps 16-32, lattice
+                                 sub-image kernel for steps >= 64, gather where none applies), 1 strict gather kernel,
+                                 2 LDS strip kernel for every step 2-32 (error if a step is unsupported), 3 experimental:
+                                 two-pass shared-weight kernel for steps 2-8 (correct, slower), 4 lane-marching kernel for
+                                 steps 2-8 + strip + lattice (what auto selects) */
     int   inputs_ready;       /* 1: in_rgb/gbuffer are complete when svgf_denoise is CALLED (no producer still pending on
                                  `stream`).  Lets the temporal pass of this frame run on an internal stream concurrently
                                  with the previous frame's trailing a-trous levels.  0: everything is ordered on `stream`. */

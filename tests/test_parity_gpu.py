@@ -142,6 +142,55 @@ def test_1080p_full_svgf_matches_oracle(pkg, orc):
     d.free(); o.free()
 
 
+@pytest.mark.parametrize("size", [(1920, 1080), (3840, 640), (333, 517), (64, 64), (40, 200), (131, 3)])
+def test_levels_6_and_7_use_lattice_kernel_and_match_oracle(pkg, orc, size):
+    """Steps 64 and 128 (levels 6-7 of the reference's 0..7 slider, src/preview.cpp:327) run on the lattice sub-image
+    kernel (svgf_atrous_lattice.hip): whole sub-images (1080p), row bands (3840 wide: 9-row bands), sub-images of one
+    pixel, images narrower than the step.  Checked against the CPU oracle and against the strict gather kernel."""
+    W, H = size
+    d = pkg.Denoiser(W, H, 0)
+    o = orc.Oracle(pkg, W, H, threads=16)
+    for f, kw in enumerate([dict(temporal_enable=1, history_level=7, blur_variance=1),
+                            dict(temporal_enable=1, history_level=6, blur_variance=0, sepcolor=1, addcolor=1)]):
+        p = pkg.reference_defaults().set(spatial_enable=1, atrous_nlevel=7, **kw)
+        c, g, cam = pkg.synth.render_frame(W, H, f, seed=41, moving=True)
+        ref = o.denoise(c, g, cam, p)
+        p.kernel_variant = 0
+        got = d.denoise_host(c, g, cam, p)
+        e = relerr(got, ref)
+        assert e.max() <= TOL_STRIP * 4 * (f + 1), f"{W}x{H} frame {f}: {e.max():.3e}"
+        assert relerr(d.read_state(2), o.read_state(2)).max() <= TOL_STRIP * 4 * (f + 1), "colour history (level 6/7 output)"
+    d.free(); o.free()
+    # the same frame through the lattice kernel and through the strict gather kernel
+    c, g, cam = pkg.synth.render_frame(W, H, 0, seed=43, moving=False)
+    outs = {}
+    for variant in (0, 1):
+        d = pkg.Denoiser(W, H, 0)
+        p = pkg.reference_defaults().set(spatial_enable=1, atrous_nlevel=7, kernel_variant=variant)
+        outs[variant] = d.denoise_host(c, g, cam, p)
+        d.free()
+    assert relerr(outs[0], outs[1]).max() <= 2e-5
+
+
+def test_lattice_kernel_keeps_the_nan_semantics(pkg, orc):
+    """A NaN position / normal texel at steps 64-128: min(1, exp(NaN)) == 1 (the `careful` path of the kernel)."""
+    W, H = 300, 200
+    c, g, cam = pkg.synth.render_frame(W, H, 0, seed=47, moving=False)
+    g = g.copy()
+    g["position"][70, 150] = np.nan
+    g["normal"][130, 20, 1] = np.inf
+    p = pkg.reference_defaults().set(spatial_enable=1, atrous_nlevel=7)
+    o = orc.Oracle(pkg, W, H, threads=8)
+    ref = o.denoise(c, g, cam, p)
+    o.free()
+    d = pkg.Denoiser(W, H, 0)
+    got = d.denoise_host(c, g, cam, p)
+    d.free()
+    both_nan = np.isnan(got) & np.isnan(ref)
+    assert np.array_equal(np.isnan(got), np.isnan(ref))
+    assert relerr(np.where(both_nan, 0, got), np.where(both_nan, 0, ref)).max() <= TOL_STRIP * 4
+
+
 def test_4k_size_independent_properties(pkg):
     """BASELINE config 4 size (3840x2160): properties that need no CPU oracle run."""
     import torch
