@@ -268,8 +268,21 @@ extern "C" int svgf_profile_enable(svgf_ctx *c, int nframes)
     c->ev = (hipEvent_t *)calloc(ne, sizeof(hipEvent_t));
     c->ev_kind = (int *)calloc((size_t)nframes * SVGF_MAX_KERNELS_PER_FRAME, sizeof(int));
     c->ev_n = (int *)calloc(nframes, sizeof(int));
-    if (!c->ev || !c->ev_kind || !c->ev_n) return SVGF_ERR_OOM;
-    for (long long k = 0; k < ne; k++) HIPC(c, hipEventCreate(&c->ev[k]));
+    if (!c->ev || !c->ev_kind || !c->ev_n) {
+        free(c->ev); free(c->ev_kind); free(c->ev_n);
+        c->ev = nullptr; c->ev_kind = nullptr; c->ev_n = nullptr;
+        return SVGF_ERR_OOM;
+    }
+    for (long long k = 0; k < ne; k++) {
+        hipError_t e = hipEventCreate(&c->ev[k]);
+        if (e != hipSuccess) {          // give back what was created: profiling stays off
+            for (long long j = 0; j < k; j++) (void)hipEventDestroy(c->ev[j]);
+            free(c->ev); free(c->ev_kind); free(c->ev_n);
+            c->ev = nullptr; c->ev_kind = nullptr; c->ev_n = nullptr;
+            snprintf(c->err, sizeof(c->err), "svgf_profile_enable: hipEventCreate failed: %s", hipGetErrorString(e));
+            return SVGF_ERR_HIP;
+        }
+    }
     c->prof_frames = nframes;
     return SVGF_OK;
 }
