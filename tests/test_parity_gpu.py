@@ -241,6 +241,41 @@ def test_device_pointers_streams_determinism_and_reset(pkg):
     d.free()
 
 
+def test_two_contexts_interleaved_on_two_streams(pkg):
+    """Contexts are independent (handle-based ABI): two denoisers of different sizes driven alternately on two streams,
+    cross-frame overlap on, give exactly what each gives alone.  Catches state that leaked into statics (LDS attribute
+    caches, segment heuristics, debug buffers) and stream mix-ups of the internal side stream."""
+    import torch
+    sizes = [(1920, 1080), (640, 360)]
+    N = 6
+    p = pkg.reference_defaults().set(temporal_enable=1, spatial_enable=1, inputs_ready=1)
+    data = []
+    for W, H in sizes:
+        frames = [pkg.synth.render_frame(W, H, f, seed=53, moving=True) for f in range(3)]
+        data.append(([torch.from_numpy(f[0]).cuda() for f in frames],
+                     [torch.from_numpy(f[1].view(np.uint8).reshape(-1)).cuda() for f in frames], [f[2] for f in frames]))
+    def run(which, streams):
+        ds = {i: pkg.Denoiser(sizes[i][0], sizes[i][1], 0) for i in which}
+        outs = {i: [torch.empty((sizes[i][1], sizes[i][0], 3), dtype=torch.float32, device="cuda") for _ in range(N)] for i in which}
+        torch.cuda.synchronize()
+        for f in range(N):
+            for i in which:
+                tin, tg, cams = data[i]
+                with torch.cuda.stream(streams[i]):
+                    ds[i].denoise(outs[i][f], tin[f % 3], tg[f % 3], cams[f % 3], p, stream=streams[i])
+        torch.cuda.synchronize()
+        res = {i: [o.cpu().numpy() for o in outs[i]] for i in which}
+        for d in ds.values():
+            d.free()
+        return res
+    s0, s1 = torch.cuda.Stream(), torch.cuda.Stream()
+    alone = {**run([0], {0: s0}), **run([1], {1: s1})}
+    both = run([0, 1], {0: s0, 1: s1})
+    for i in (0, 1):
+        for f in range(N):
+            assert np.array_equal(both[i][f], alone[i][f]), f"context {i} frame {f} differs when interleaved with the other context"
+
+
 @pytest.mark.parametrize("history_level", [0, 1, 3, 5])
 def test_cross_frame_overlap_is_bit_identical(pkg, history_level):
     """inputs_ready=1 lets the temporal pass of frame f+1 run concurrently with the trailing a-trous levels of frame f
