@@ -460,7 +460,8 @@ extern "C" int svgf_denoise(svgf_ctx *c, void *out_rgb_dev, const void *in_rgb_d
             AtrousArgs a;
             a.src = c->cv[src]; a.dst = dst >= 0 ? c->cv[dst] : nullptr; a.out_rgb = last ? out : nullptr;
             a.nrm = c->nrm[gnew]; a.pos = c->pos[gnew]; a.gbuf = g;
-            a.W = c->W; a.H = c->H; a.step = 1 << level;        // level starts at 1 => steps 2,4,8,16,32 (:98,386)
+            a.W = c->W; a.H = c->H;
+            a.step = 1 << (p->paper_steps ? level - 1 : level);   // reference: level starts at 1 => steps 2,4,8,16,32 (:98,386)
             a.sigma_c = p->sigma_l; a.sigma_n = p->sigma_n; a.sigma_x = p->sigma_x;
             a.blur_variance = p->blur_variance ? 1 : 0;
             a.modulate = (last && p->sepcolor && p->addcolor) ? 1 : 0;

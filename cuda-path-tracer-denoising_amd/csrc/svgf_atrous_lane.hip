@@ -740,7 +740,7 @@ hipError_t launch_lane_cfg(const AtrousArgs &a, hipStream_t s)
 
 bool atrous_lane_supported(const AtrousArgs &a)
 {
-    if (a.step != 2 && a.step != 4 && a.step != 8) return false;
+    if (a.step != 1 && a.step != 2 && a.step != 4 && a.step != 8) return false;   // step 1: SvgfParams::paper_steps
     if ((long long)a.W * a.H * 16 >= (1LL << 32)) return false;
     return true;
 }
@@ -748,6 +748,7 @@ bool atrous_lane_supported(const AtrousArgs &a)
 hipError_t launch_atrous_lane(const AtrousArgs &a, hipStream_t s)
 {
     switch (a.step) {
+    case 1: return a.dst ? launch_lane_cfg<0, true>(a, s) : launch_lane_cfg<0, false>(a, s);
     case 2: return a.dst ? launch_lane_cfg<1, true>(a, s) : launch_lane_cfg<1, false>(a, s);
     case 4: return a.dst ? launch_lane_cfg<2, true>(a, s) : launch_lane_cfg<2, false>(a, s);
     case 8: return a.dst ? launch_lane_cfg<3, true>(a, s) : launch_lane_cfg<3, false>(a, s);

@@ -741,7 +741,7 @@ void pick(int log2s, int W, int &tx, int &rows)
 
 bool atrous_strip_supported(const AtrousArgs &a)
 {
-    if (a.step < 2 || a.step > 32 || (a.step & (a.step - 1))) return false;
+    if (a.step < 1 || a.step > 32 || (a.step & (a.step - 1))) return false;      // step 1: SvgfParams::paper_steps
     if ((long long)a.W * a.H * 16 >= (1LL << 32)) return false;   // 32-bit element offsets in the kernel
     return true;
 }
@@ -755,6 +755,7 @@ hipError_t launch_atrous_strip(const AtrousArgs &a, hipStream_t s)
     int tx, rows;
     pick(log2s, a.W, tx, rows);
     STRIP_CASE(1, 256, 3) STRIP_CASE(2, 256, 3) STRIP_CASE(3, 256, 3)
+    STRIP_CASE(0, 128, 1) STRIP_CASE(0, 128, 2) STRIP_CASE(0, 256, 1) STRIP_CASE(0, 256, 2) STRIP_CASE(0, 256, 3)
     STRIP_CASE(1, 128, 1) STRIP_CASE(1, 128, 2) STRIP_CASE(1, 256, 1) STRIP_CASE(1, 256, 2)
     STRIP_CASE(2, 128, 1) STRIP_CASE(2, 128, 2) STRIP_CASE(2, 256, 1) STRIP_CASE(2, 256, 2)
     STRIP_CASE(3, 128, 1) STRIP_CASE(3, 128, 2) STRIP_CASE(3, 256, 1) STRIP_CASE(3, 256, 2)

@@ -28,7 +28,7 @@ extern "C" {
 #endif
 
 #define SVGF_VERSION_MAJOR 0
-#define SVGF_VERSION_MINOR 1
+#define SVGF_VERSION_MINOR 2
 
 /* ---- error codes (every entry point returns one of these; the library never exits) ---- */
 #define SVGF_OK                 0
@@ -89,6 +89,9 @@ typedef struct SvgfParams {
                                  of view and aspect ratio.  0 = the reference's mapping (src/denoise.cu:202-203: "no
                                  tan(fov), no aspect", exact only for tan(FOVY) = 1 and W = H; at 16:9 a static camera
                                  keeps its history on ~16 % of the pixels) */
+    int   paper_steps;        /* "next" row f4: 1 = a-trous level k (1-based) uses dilation 2^(k-1) = 1, 2, 4, ... as in the
+                                 SVGF paper; 0 = the reference's 2^k = 2, 4, 8, ... (its level counter starts at 1,
+                                 src/denoise.cu:98,386).  Appended in ABI 0.2 (sizeof(SvgfParams) 68 -> 72). */
 } SvgfParams;
 
 #define SVGF_MAX_LEVELS 10

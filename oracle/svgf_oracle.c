@@ -480,12 +480,14 @@ int svgf_oracle_denoise(oracle_ctx *c, float *out, const float *in, const SvgfGB
         for (int level = 1; level <= p->atrous_nlevel; level++) {
             const float *src = (level == 1) ? c->color_history : c->temp[level % 2];
             float *dst = (level == p->atrous_nlevel) ? out : c->temp[(level + 1) % 2];
+            /* dilation exponent: the reference's 2^level, or 2^(level-1) with SvgfParams::paper_steps (extension, f4) */
+            const int lexp = p->paper_steps ? level - 1 : level;
             if (c->variance_mode == ORACLE_VARIANCE_INPLACE) {
-                svgf_oracle_atrous(src, dst, c->variance, c->variance, g, W, H, level, level == p->atrous_nlevel,
+                svgf_oracle_atrous(src, dst, c->variance, c->variance, g, W, H, lexp, level == p->atrous_nlevel,
                                    p->sigma_l, p->sigma_n, p->sigma_x, p->blur_variance, addcolor, 1, 1);
             } else {
                 memcpy(c->variance_tmp, c->variance, n * sizeof(float));
-                svgf_oracle_atrous(src, dst, c->variance_tmp, c->variance, g, W, H, level, level == p->atrous_nlevel,
+                svgf_oracle_atrous(src, dst, c->variance_tmp, c->variance, g, W, H, lexp, level == p->atrous_nlevel,
                                    p->sigma_l, p->sigma_n, p->sigma_x, p->blur_variance, addcolor, 0, c->nthreads);
             }
             if (level == p->history_level) memcpy(c->color_history, dst, n * 3 * sizeof(float));
