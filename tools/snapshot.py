@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--moving", action="store_true")
     ap.add_argument("--scene", default=None, help="scene text file (reference format): primitives rendered by svgf_scene_render")
     ap.add_argument("--exact-reprojection", action="store_true", help="SvgfParams::reproj_scale = (tan(fovy) W/H, tan(fovy))")
+    ap.add_argument("--paper-steps", action="store_true", help="SvgfParams::paper_steps: dilations 1,2,4,8,16 instead of 2..32")
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "side_by_side.png"))
     a = ap.parse_args()
     import torch
@@ -27,6 +28,8 @@ def main():
     W, H = map(int, a.size.split("x"))
     den = pkg.Denoiser(W, H)
     params = pkg.reference_defaults().set(temporal_enable=1, spatial_enable=1, atrous_nlevel=5, history_level=1)
+    if a.paper_steps:
+        params.paper_steps = 1
     if a.exact_reprojection:
         plx, ply = pkg.synth._pixel_length(W, H, 45.0)
         params.reproj_scale[0], params.reproj_scale[1] = float(plx) * W / 2.0, float(ply) * H / 2.0
