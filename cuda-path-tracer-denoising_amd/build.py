@@ -45,7 +45,16 @@ def build_hip(force: bool = False) -> str:
         return LIB
     tmp = LIB + f".tmp{os.getpid()}"
     extra = os.environ.get("SVGF_EXTRA_HIPCC_FLAGS", "").split()      # kernel experiments only (tools/, profiles/)
-    _run([hipcc_path()] + HIPCC_FLAGS + extra + srcs + ["-o", tmp])
+    # one hipcc -c per translation unit, in parallel (the a-trous kernels are template-heavy: ~70 s serial, ~30 s so),
+    # objects in a scratch directory, then one link
+    import concurrent.futures
+    import tempfile
+    cflags = [f for f in HIPCC_FLAGS if f != "-shared"]
+    with tempfile.TemporaryDirectory(prefix="svgf_build_") as scratch:
+        objs = [os.path.join(scratch, os.path.basename(x) + ".o") for x in srcs]
+        with concurrent.futures.ThreadPoolExecutor(max_workers=min(len(srcs), os.cpu_count() or 1)) as pool:
+            list(pool.map(lambda so: _run([hipcc_path()] + cflags + extra + ["-c", so[0], "-o", so[1]]), zip(srcs, objs)))
+        _run([hipcc_path(), "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", tmp])
     os.replace(tmp, LIB)              # atomic: concurrent ranks never see a half-written library
     return LIB
 
