@@ -15,6 +15,9 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--size", default="1920x1080")
     ap.add_argument("--frames", type=int, default=2000)
+    ap.add_argument("--random", type=int, default=0, metavar="K",
+                    help="every K frames draw new parameters (levels 0..8, history level, paper steps, pre-blur, debug views, "
+                         "temporal on/off) for both contexts")
     a = ap.parse_args()
     import torch
     pkg = ge.load_package()
@@ -34,8 +37,17 @@ def main():
     ob = [torch.empty((H, W, 3), dtype=torch.float32, device="cuda") for _ in range(2)]
     sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
     bad = 0
+    import random
+    rng = random.Random(20260928)
     for f in range(a.frames):
         k = f % nbuf
+        if a.random and f % a.random == 0 and f > 0:
+            nl = rng.randint(0, 8)
+            kw = dict(atrous_nlevel=nl, history_level=rng.randint(0, nl + 1), paper_steps=rng.randint(0, 1),
+                      blur_variance=rng.randint(0, 1), right_view_option=rng.choice([0, 0, 0, 0, 1, 2]),
+                      temporal_enable=rng.choice([1, 1, 1, 0]), spatial_enable=rng.choice([1, 1, 1, 0]),
+                      sepcolor=rng.randint(0, 1), addcolor=rng.randint(0, 1))
+            pa.set(**kw); pb.set(**kw)
         da.denoise(oa[f & 1], rgb[k], gb[k], cams[k], pa, stream=sa)      # no synchronisation between calls
         db.denoise(ob[f & 1], rgb[k], gb[k], cams[k], pb, stream=sb)
         if f % 97 == 96 or f == a.frames - 1:
