@@ -69,6 +69,8 @@ def main():
                          "configs[0]: 800x800, temporal off, one a-trous level, CPU leg single-threaded")
     ap.add_argument("--kernel-variant", type=int, default=0,
                     help="SvgfParams::kernel_variant (0 = the library's default choice; 2 strip, 4 lane-marching kernel ...)")
+    ap.add_argument("--no-overlap", action="store_true",
+                    help="SvgfParams::inputs_ready = 0: everything ordered on one stream (A/B of the cross-frame overlap)")
     ap.add_argument("--host-inputs", action="store_true",
                     help="render the synthetic frames with numpy and upload them (default: the device-side producer, "
                          "svgf_synth_render, SURVEY.md 8f row f1; both give the same frames bit for bit)")
@@ -104,7 +106,7 @@ def main():
         dist.barrier()
     pkg = ge.load_package()
     params = pkg.reference_defaults().set(temporal_enable=1, spatial_enable=1, atrous_nlevel=NLEVEL, history_level=1,
-                                          inputs_ready=1)   # inputs are resident in HBM before each call
+                                          inputs_ready=0 if a.no_overlap else 1)   # inputs are resident in HBM before each call
     params.set(kernel_variant=a.kernel_variant)
     if a.config == "config1":   # BASELINE configs[0]: the reference's own CPU-runnable case
         params.set(temporal_enable=0, atrous_nlevel=1)
