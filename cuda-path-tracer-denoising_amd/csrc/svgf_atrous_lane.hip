@@ -33,6 +33,9 @@
 #ifndef SVGF_LANE_G2
 #define SVGF_LANE_G2 2      // where the second forward row's geometry is read: 0 one row ahead, 1 mid-row, 2 not ahead
 #endif
+#ifndef SVGF_LANE_SPLIT_PROLOGUE
+#define SVGF_LANE_SPLIT_PROLOGUE 1
+#endif
 #ifndef SVGF_LANE_G1
 #define SVGF_LANE_G1 1      // first forward row's geometry read one row ahead (1) or not (0)
 #endif
@@ -135,6 +138,17 @@ __global__ __launch_bounds__(NT) void k_atrous_lane(AtrousArgs a, LaneGeom gm)
         (void)id; (void)dbg_it;
 #endif
     };
+
+    // prologue marks of the timeline: slot 7 of iteration 0 = kernel entry, of iteration 1 = prologue barrier passed
+    auto stamp_at = [&](int it_slot) {
+#ifdef SVGF_LANE_TIMELINE
+        if (gm.dbg && bid == gm.dbg_block && (tid & 63) == 0)
+            gm.dbg[((tid >> 6) * 16 + it_slot) * 8 + 7] = __builtin_amdgcn_s_memtime();
+#else
+        (void)it_slot;
+#endif
+    };
+    stamp_at(0);
 
     // ring slot of lattice row br: `ring_base` is the slot of row ring_b - 2 (wave-uniform, advanced once per iteration)
     int ring_base = 0, ring_b = b0;
@@ -284,6 +298,31 @@ __global__ __launch_bounds__(NT) void k_atrous_lane(AtrousArgs a, LaneGeom gm)
         }
     };
 
+#if SVGF_LANE_SPLIT_PROLOGUE
+    // ---------------- prologue in two steps.  All 256 workgroups start at once and each wants five ring rows, a 25 MB
+    // burst that takes ~4 us to arrive.  The first warm-up row only needs rows b0-2 .. b0: every thread helps stage those
+    // (and the pre-blur rows of iteration 0), the loader threads queue the loads of rows b0+1, b0+2 behind them and
+    // publish them at a second barrier, which the compute waves reach after the first warm-up row. ----------
+    {
+        constexpr int N = (3 * RW + NT - 1) / NT;
+        Px px[N];
+        rows_load(px, b0 - 2, 3, tid, NT);
+        constexpr int NB = (2 * BW + NT - 1) / NT;
+        float bv[NB];
+        blur_load(bv, b0, tid, NT);
+        constexpr int N2 = (2 * RW + kLoaderThreads - 1) / kLoaderThreads;
+        Px px2[N2];
+        if (is_loader) rows_load(px2, b0 + 1, 2, tid - NC, kLoaderThreads);
+        rows_store(px);
+        if (a.blur_variance) blur_store(bv, 0, tid, NT);
+        __syncthreads();
+        stamp_at(1);
+        if (is_loader) {
+            rows_store(px2);
+            __syncthreads();
+        }
+    }
+#else
     // ---------------- prologue: every thread helps stage rows b0-2 .. b0+2 and the pre-blur rows of iteration 0 ----------
     {
         constexpr int N = (5 * RW + NT - 1) / NT;
@@ -296,6 +335,8 @@ __global__ __launch_bounds__(NT) void k_atrous_lane(AtrousArgs a, LaneGeom gm)
         if (a.blur_variance) blur_store(bv, 0, tid, NT);
     }
     __syncthreads();
+    stamp_at(1);
+#endif
 
     if (is_loader) {
         // ================================ loader waves (as in the strip kernel) ================================
@@ -460,12 +501,17 @@ __global__ __launch_bounds__(NT) void k_atrous_lane(AtrousArgs a, LaneGeom gm)
     // ---- warm-up: rows b0-2 and b0-1 publish their forward terms (no output, no new ring rows needed) ----
 #pragma unroll 1
     for (int bw = b0 - 2; bw < b0; bw++) {
+#if SVGF_LANE_SPLIT_PROLOGUE
+        if (bw == b0 - 1) __syncthreads();            // rows b0+1, b0+2 are published by the loader threads (see the prologue)
+#endif
         const char *rowc = colbase + slot_of(bw) * ROWB + 2 * PXB;
         const v4f A = *reinterpret_cast<const v4f *>(rowc);
         const v4f B = *reinterpret_cast<const v4f *>(rowc + 16);
-        float F1[5], F2[5];
+        float F1[5] = { 0.0f, 0.0f, 0.0f, 0.0f, 0.0f }, F2[5];
 #pragma unroll
         for (int j = 1; j <= 2; j++) {
+            // the terms row b0-2 shares with row b0-1 are never consumed (b0-1 is not an output row)
+            if (j == 1 && bw == b0 - 2) continue;
             const char *rowp = colbase + slot_of(bw + j) * ROWB;
 #pragma unroll
             for (int i = 0; i < 5; i++) {
@@ -723,6 +769,9 @@ hipError_t launch_lane_cfg(const AtrousArgs &a, hipStream_t s)
             const int show[4] = { 0, NWC - 1, NWC, NWC + 3 };
             for (int si = 0; si < 4; si++) {
                 const int w = show[si];
+                if (h[(w * 16) * 8 + 7])
+                    fprintf(stderr, "  wave %2d prologue: entry .. barrier passed %6llu, .. first iteration %6llu ticks\n", w,
+                            h[(w * 16 + 1) * 8 + 7] - h[(w * 16) * 8 + 7], h[(w * 16) * 8 + 0] - h[(w * 16) * 8 + 7]);
                 for (int it = 0; it < 8 && h[(w * 16 + it) * 8]; it++) {
                     unsigned long long *t = &h[(w * 16 + it) * 8];
                     if (w >= NWC) fprintf(stderr, "  loader %2d it %2d: t0=%6llu work %6llu barrier %5llu\n", w, it, t[0] - h[0], t[5] - t[0], t[6] - t[5]);
