@@ -111,6 +111,14 @@ __global__ __launch_bounds__(NT) void k_atrous_lane(AtrousArgs a, LaneGeom gm)
     float *blur = reinterpret_cast<float *>(smem + RING_BYTES);           // [iteration parity][y-1 | y+1][phase][BM]
     int *nan_seen = reinterpret_cast<int *>(smem + RING_BYTES + 2 * BLUR_BUF * 4);
 
+    // Every kernel argument is fetched by ONE batch of s_loads at entry.  Left to itself the compiler fetches them where
+    // control flow first needs them — LaneGeom for the work-item decode, W/H behind the first early return, the plane
+    // pointers behind the second — three dependent scalar-memory round trips (several hundred cycles each, cold) in
+    // front of the first global load of the prologue.
+    asm volatile("" :: "s"(a.src), "s"(a.dst), "s"(a.out_rgb), "s"(a.nrm), "s"(a.pos), "s"(a.gbuf), "s"(a.W), "s"(a.H),
+                 "s"(a.sigma_c), "s"(a.blur_variance), "s"(a.modulate), "s"(gm.n_strips), "s"(gm.n_segs), "s"(gm.seg_rows),
+                 "s"(gm.n_groups), "s"(gm.kn), "s"(gm.kx));
+
     // ---- work item: (strip, y-phase, segment) as in the strip kernel ----
     const int bid = blockIdx.x;
     const int xcd = bid & 7, kk = bid >> 3;
@@ -238,24 +246,27 @@ __global__ __launch_bounds__(NT) void k_atrous_lane(AtrousArgs a, LaneGeom gm)
     int l_xq[ML], l_lds[ML];
     int b_voff[MBL], b_lds[MBL];      // b_voff < 0: element does not exist or its column is outside the image
     bool b_d[MBL];
-    if (is_loader) {
+    // (filled in inside the prologue, between the issue of its global loads and their use)
+    auto loader_invariants = [&]() {
+        if (is_loader) {
 #pragma unroll
-        for (int m = 0; m < ML; m++) {
-            const int xi = min(llane + m * kLoaderGroup, RW - 1);
-            const int xs = x0 - 2 * S + xi;
-            l_xq[m] = min(max(xs, 0), W - 1);
-            l_lds[m] = rec_of(xi) | ((xs >= 0 && xs < W) ? 0 : 0x40000000);
-        }
+            for (int m = 0; m < ML; m++) {
+                const int xi = min(llane + m * kLoaderGroup, RW - 1);
+                const int xs = x0 - 2 * S + xi;
+                l_xq[m] = min(max(xs, 0), W - 1);
+                l_lds[m] = rec_of(xi) | ((xs >= 0 && xs < W) ? 0 : 0x40000000);
+            }
 #pragma unroll
-        for (int m = 0; m < MBL; m++) {
-            const int e = llane + m * kLoaderGroup;
-            const int d = e / BW, xb = e - d * BW;
-            const int xs = x0 - 1 + xb;
-            b_d[m] = (d != 0);
-            b_lds[m] = (e < 2 * BW) ? (d * BLUR_ROW + bel_of(xb)) : -1;
-            b_voff[m] = (e < 2 * BW && xs >= 0 && xs < W) ? (xs * 16 + 12) : -1;
+            for (int m = 0; m < MBL; m++) {
+                const int e = llane + m * kLoaderGroup;
+                const int d = e / BW, xb = e - d * BW;
+                const int xs = x0 - 1 + xb;
+                b_d[m] = (d != 0);
+                b_lds[m] = (e < 2 * BW) ? (d * BLUR_ROW + bel_of(xb)) : -1;
+                b_voff[m] = (e < 2 * BW && xs >= 0 && xs < W) ? (xs * 16 + 12) : -1;
+            }
         }
-    }
+    };
     // iteration j outputs row b0 + j and newly needs lattice row b0 + j + 2
     auto loader_issue = [&](int j) {
         const int bo = b0 + j;
@@ -299,28 +310,34 @@ __global__ __launch_bounds__(NT) void k_atrous_lane(AtrousArgs a, LaneGeom gm)
     };
 
 #if SVGF_LANE_SPLIT_PROLOGUE
-    // ---------------- prologue in two steps.  All 256 workgroups start at once and each wants five ring rows, a 25 MB
-    // burst that takes ~4 us to arrive.  The first warm-up row only needs rows b0-2 .. b0: every thread helps stage those
-    // (and the pre-blur rows of iteration 0), the loader threads queue the loads of rows b0+1, b0+2 behind them and
-    // publish them at a second barrier, which the compute waves reach after the first warm-up row. ----------
-    {
-        constexpr int N = (3 * RW + NT - 1) / NT;
-        Px px[N];
-        rows_load(px, b0 - 2, 3, tid, NT);
-        constexpr int NB = (2 * BW + NT - 1) / NT;
-        float bv[NB];
-        blur_load(bv, b0, tid, NT);
+    // ---------------- prologue in two steps.  All 256 workgroups start at once and each wants five ring rows, a burst that
+    // takes 3-4 us to arrive.  The first warm-up row only needs rows b0-2 .. b0: the compute waves stage those (and the
+    // pre-blur rows of iteration 0) and pass barrier A as soon as THEIR loads have landed; the loader waves fetch rows
+    // b0+1, b0+2 at the same time, compute their invariants while the loads fly, pass barrier A without waiting for them
+    // and publish the two rows at barrier B, which the compute waves reach after the first warm-up row.  The two paths
+    // are separate straight-line code (a join in between makes the compiler park loaded registers behind s_waitcnt 0). --
+    if (is_loader) {
         constexpr int N2 = (2 * RW + kLoaderThreads - 1) / kLoaderThreads;
         Px px2[N2];
-        if (is_loader) rows_load(px2, b0 + 1, 2, tid - NC, kLoaderThreads);
-        rows_store(px);
-        if (a.blur_variance) blur_store(bv, 0, tid, NT);
-        __syncthreads();
+        rows_load(px2, b0 + 1, 2, tid - NC, kLoaderThreads);
+        stamp_at(2);
+        loader_invariants();
+        __syncthreads();                // A
         stamp_at(1);
-        if (is_loader) {
-            rows_store(px2);
-            __syncthreads();
-        }
+        rows_store(px2);
+        __syncthreads();                // B
+    } else {
+        constexpr int N = (3 * RW + NC - 1) / NC;
+        Px px[N];
+        rows_load(px, b0 - 2, 3, tid, NC);
+        constexpr int NB = (2 * BW + NC - 1) / NC;
+        float bv[NB];
+        blur_load(bv, b0, tid, NC);
+        stamp_at(2);
+        rows_store(px);
+        if (a.blur_variance) blur_store(bv, 0, tid, NC);
+        __syncthreads();                // A
+        stamp_at(1);
     }
 #else
     // ---------------- prologue: every thread helps stage rows b0-2 .. b0+2 and the pre-blur rows of iteration 0 ----------
@@ -331,6 +348,7 @@ __global__ __launch_bounds__(NT) void k_atrous_lane(AtrousArgs a, LaneGeom gm)
         constexpr int NB = (2 * BW + NT - 1) / NT;
         float bv[NB];
         blur_load(bv, b0, tid, NT);
+        loader_invariants();
         rows_store(px);
         if (a.blur_variance) blur_store(bv, 0, tid, NT);
     }
@@ -770,8 +788,9 @@ hipError_t launch_lane_cfg(const AtrousArgs &a, hipStream_t s)
             for (int si = 0; si < 4; si++) {
                 const int w = show[si];
                 if (h[(w * 16) * 8 + 7])
-                    fprintf(stderr, "  wave %2d prologue: entry .. barrier passed %6llu, .. first iteration %6llu ticks\n", w,
-                            h[(w * 16 + 1) * 8 + 7] - h[(w * 16) * 8 + 7], h[(w * 16) * 8 + 0] - h[(w * 16) * 8 + 7]);
+                    fprintf(stderr, "  wave %2d prologue: entry .. loads issued %6llu, .. barrier passed %6llu, .. first iteration %6llu ticks\n", w,
+                            h[(w * 16 + 2) * 8 + 7] - h[(w * 16) * 8 + 7], h[(w * 16 + 1) * 8 + 7] - h[(w * 16) * 8 + 7],
+                            h[(w * 16) * 8 + 0] - h[(w * 16) * 8 + 7]);
                 for (int it = 0; it < 8 && h[(w * 16 + it) * 8]; it++) {
                     unsigned long long *t = &h[(w * 16 + it) * 8];
                     if (w >= NWC) fprintf(stderr, "  loader %2d it %2d: t0=%6llu work %6llu barrier %5llu\n", w, it, t[0] - h[0], t[5] - t[0], t[6] - t[5]);

@@ -167,6 +167,12 @@ __global__ __launch_bounds__(TX * ROWS + loader_threads(TX, ROWS)) void k_atrous
     float *blur = reinterpret_cast<float *>(smem + RING_BYTES);
     int *nan_seen = reinterpret_cast<int *>(smem + RING_BYTES + BLUR_FLOATS * 4);
 
+    // every kernel argument in one batch of s_loads at entry (see svgf_atrous_lane.hip: three dependent scalar-memory round
+    // trips in front of the prologue's first global load otherwise)
+    asm volatile("" :: "s"(a.src), "s"(a.dst), "s"(a.out_rgb), "s"(a.nrm), "s"(a.pos), "s"(a.gbuf), "s"(a.W), "s"(a.H),
+                 "s"(a.sigma_c), "s"(a.blur_variance), "s"(a.modulate), "s"(gm.n_strips), "s"(gm.n_segs), "s"(gm.seg_rows),
+                 "s"(gm.n_groups), "s"(gm.kn), "s"(gm.kx));
+
     // ---- work item: (strip, y-phase, segment); all strips of one (phase, segment) share an XCD's L2 ----
     const int bid = blockIdx.x;
     const int xcd = bid & 7, k = bid >> 3;
@@ -298,23 +304,26 @@ __global__ __launch_bounds__(TX * ROWS + loader_threads(TX, ROWS)) void k_atrous
     int l_rr[ML];       // which of the ROWS new rows the pixel belongs to
     int b_voff[NBT];    // byte offset of {clamped column}.w inside a source row
     bool b_ok[NBT];
-    if (is_loader) {
+    // (filled in inside the prologue, between the issue of its global loads and their use)
+    auto loader_invariants = [&]() {
+        if (is_loader) {
 #pragma unroll
-        for (int m = 0; m < ML; m++) {
-            const int idx = min(llane + m * kLoaderGroup, ROWS * RW - 1);   // surplus lanes repeat the last pixel
-            const int rr = idx / RW, xi = idx - rr * RW;
-            const int xs = x0 - 2 * S + xi;
-            l_xq[m] = min(max(xs, 0), W - 1);
-            l_lds[m] = (xi * PXB) | ((xs >= 0 && xs < W) ? 0 : 0x40000000);
-            l_rr[m] = rr;
-        }
+            for (int m = 0; m < ML; m++) {
+                const int idx = min(llane + m * kLoaderGroup, ROWS * RW - 1);   // surplus lanes repeat the last pixel
+                const int rr = idx / RW, xi = idx - rr * RW;
+                const int xs = x0 - 2 * S + xi;
+                l_xq[m] = min(max(xs, 0), W - 1);
+                l_lds[m] = (xi * PXB) | ((xs >= 0 && xs < W) ? 0 : 0x40000000);
+                l_rr[m] = rr;
+            }
 #pragma unroll
-        for (int t = 0; t < NBT; t++) {
-            const int xs = x0 - 1 + llane + t * kLoaderGroup;
-            b_ok[t] = (xs >= 0 && xs < W);
-            b_voff[t] = min(max(xs, 0), W - 1) * 16 + 12;
+            for (int t = 0; t < NBT; t++) {
+                const int xs = x0 - 1 + llane + t * kLoaderGroup;
+                b_ok[t] = (xs >= 0 && xs < W);
+                b_voff[t] = min(max(xs, 0), W - 1) * 16 + 12;
+            }
         }
-    }
+    };
     // blur value number NBC*NBT: columns TX, TX+1 of every combination, one per lane (lanes 0 .. 2*NBC-1)
     auto blur_extra_coords = [&](int bcj, int &c, int &xi, bool &ok, unsigned &q) {
         c = llane >> 1;
@@ -408,6 +417,7 @@ __global__ __launch_bounds__(TX * ROWS + loader_threads(TX, ROWS)) void k_atrous
         float bv[MB];
         blur_load(bv, b0, tid, NT);
         stamp(1);
+        loader_invariants();            // independent of the loads in flight
         rows_store(px);
         if (a.blur_variance) blur_store(bv, 0, tid, NT);
         stamp(4);
