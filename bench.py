@@ -34,7 +34,17 @@ FRAME_BYTES_PER_PIXEL = 404.0      # temporal 124 + 5 x 56
 HBM_PEAK_GBS = 8000.0              # MI355X_MICROARCH.md: 8 TB/s spec
 
 
-def cpu_baseline(pkg, frames, params, budget_s=25.0, threads=None, what="full-SVGF"):
+def kernel_sources_sha16():
+    """Fingerprint of the a-trous kernel sources the PMC traffic record belongs to."""
+    import hashlib
+    h = hashlib.sha256()
+    for name in ("svgf_atrous_lane.hip", "svgf_atrous_strip.hip", "svgf_api.hip"):
+        with open(os.path.join(ROOT, "cuda-path-tracer-denoising_amd", "csrc", name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def cpu_baseline(pkg, frames, params, budget_s=25.0, threads=None, what="full-SVGF", all_cores=True):
     """CPU oracle (oracle/svgf_oracle.c, OpenMP) on the same workload, bounded sample."""
     orc = ge.load_oracle()
     cores = os.cpu_count() or 1
@@ -52,9 +62,22 @@ def cpu_baseline(pkg, frames, params, budget_s=25.0, threads=None, what="full-SV
         if time.perf_counter() - t_start > budget_s and n >= 1:
             break
     o.free()
-    return {"value": round(W * H / (t_all / n) / 1e6, 3), "unit": "Mpixels/s", "cores": threads, "kind": "port",
-            "sample": f"{n} steady-state frames of the same {W}x{H} {what} workload, oracle/svgf_oracle.c "
-                      f"(gcc -O2, OpenMP over rows, {threads} threads of {cores} host cores)"}
+    res = {"value": round(W * H / (t_all / n) / 1e6, 3), "unit": "Mpixels/s", "cores": threads, "kind": "port",
+           "sample": f"{n} steady-state frames of the same {W}x{H} {what} workload, oracle/svgf_oracle.c "
+                     f"(gcc -O2, OpenMP over rows, {threads} threads of {cores} host cores)"}
+    if all_cores and cores > threads:        # north_star: "the same box's host cores" — every core, next to the 64-thread figure
+        oa = orc.Oracle(pkg, W, H, threads=cores)
+        ts = []
+        for f in range(3):
+            c, g, cam = frames[f % len(frames)]
+            t0 = time.perf_counter()
+            oa.denoise(c, g, cam, params)
+            if f >= 1:
+                ts.append(time.perf_counter() - t0)
+        oa.free()
+        res["all_cores"] = {"value": round(W * H / (sum(ts) / len(ts)) / 1e6, 3), "unit": "Mpixels/s", "cores": cores,
+                            "sample": f"{len(ts)} steady-state frames, OpenMP over rows on all {cores} host cores"}
+    return res
 
 
 def main():
@@ -74,9 +97,28 @@ def main():
     ap.add_argument("--host-inputs", action="store_true",
                     help="render the synthetic frames with numpy and upload them (default: the device-side producer, "
                          "svgf_synth_render, SURVEY.md 8f row f1; both give the same frames bit for bit)")
+    ap.add_argument("--min-warmup-seconds", type=float, default=0.6,
+                    help="untimed steps continue after --warmup until this much wall time has passed (clock ramp, history "
+                         "fill): a --steps 20 run then measures what a --steps 200 run measures")
     a = ap.parse_args()
 
     import torch
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: become the launcher — one process per GPU, same rendezvous torchrun would set up
+        if not torch.cuda.is_available() or torch.cuda.device_count() < a.gpus:
+            raise SystemExit(f"bench.py --gpus {a.gpus}: only {torch.cuda.device_count() if torch.cuda.is_available() else 0} GPU(s) visible")
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        procs = []
+        for r in range(a.gpus):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), MASTER_ADDR="127.0.0.1",
+                       MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+        rcs = [p.wait() for p in procs]
+        raise SystemExit(max(rcs))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -141,8 +183,13 @@ def main():
         return W * H
 
     # warm-up is run with profiling slots too, then the frame counter restarts so slots hold the timed steps only
-    for i in range(a.warmup):
-        step(i)
+    t_w = time.perf_counter()
+    n_w = 0
+    while n_w < a.warmup or time.perf_counter() - t_w < a.min_warmup_seconds:
+        step(n_w)
+        n_w += 1
+        if n_w % 32 == 0:
+            torch.cuda.synchronize(dev)
     torch.cuda.synchronize(dev)
     den.profile_enable(a.steps)
     dt, pixels = pkg.farm.timed_region(step, a.steps, 0, lambda: torch.cuda.synchronize(dev), dist=dist, device=dev)
@@ -174,10 +221,15 @@ def main():
                      if kind == pkg.binding.KERNEL_ATROUS]
 
     if rank == 0:
-        traffic = None
-        try:   # HBM bytes per launch from the committed PMC passes (profiles/pmc_traffic.json); not re-measured live
+        traffic, traffic_note = None, "no PMC record"
+        try:   # HBM bytes per launch from the committed PMC passes (profiles/pmc_traffic.json).  Counter passes cannot run
+            # inside the timed region, so the figure is only reported while the kernels it was measured on are unchanged.
             with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-                traffic = json.load(f)["mean_bytes_per_launch"]
+                rec = json.load(f)
+            if rec.get("kernel_sources_sha16") == kernel_sources_sha16():
+                traffic, traffic_note = rec["mean_bytes_per_launch"], "measured on these kernel sources (sha16 " + rec["kernel_sources_sha16"] + ")"
+            else:
+                traffic_note = "dropped: the a-trous kernel sources changed since the PMC passes (profiles/pmc_traffic.json)"
         except Exception:
             traffic = None
         value = pixels / dt / 1e6
@@ -190,6 +242,7 @@ def main():
                        else "SVGF Mpixels/s (full pipeline) at 4K; \u00e0-trous HBM GB/s vs roofline" if a.config.startswith("4k")
                        else "SVGF Mpixels/s (full pipeline) at 1080p; \u00e0-trous HBM GB/s vs roofline"),
             "value": round(value, 2), "unit": "Mpixels/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "warmup_steps_run": n_w,
             "ms_per_step": round(dt / a.steps * 1e3, 5), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": (f"cornell-like {W}x{H}, variance fill + ONE a-trous level (temporal off), " if a.config == "config1" else
@@ -200,6 +253,7 @@ def main():
                        "parallelism": f"replicas{world}"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "traffic_measured_live": False, "traffic_provenance": traffic_note,
                          "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, profiles/pmc_traffic.json (FETCH x2 per MI355X_MICROARCH.md)",
                          "kernel": "one a-trous level: k_atrous_lane (steps 2-8), k_atrous_strip (steps 16-32); mean over the 5 launches of a frame", "bytes_per_launch": ATROUS_BYTES_PER_PIXEL * W * H,
                          "mean_launch_us": round(a_ms * 1e3, 2), "launches_timed": len(atrous_ms),
@@ -227,7 +281,7 @@ def main():
                           for f in range(min(nsrc, 4))]
             host_frames = [(f[0], f[1], f[2]) for f in frames]
             if a.config == "config1":   # "single-threaded" is how BASELINE.json words this configuration
-                line["cpu_baseline"] = cpu_baseline(pkg, host_frames, params, threads=1, what="one-level non-temporal")
+                line["cpu_baseline"] = cpu_baseline(pkg, host_frames, params, threads=1, what="one-level non-temporal", all_cores=False)
             else:
                 line["cpu_baseline"] = cpu_baseline(pkg, host_frames, params)
         print(json.dumps(line), flush=True)

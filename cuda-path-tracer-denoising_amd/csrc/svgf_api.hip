@@ -21,6 +21,9 @@ struct svgf_ctx {
     int device, W, H;
     size_t n;
     float4 *cv[4];
+    float *vp[4];          // zero-margined (W+2) x (H+2) copies of cv[k].w for the pre-blur of the per-wave a-trous kernel
+    unsigned vp_valid;     // bit k: vp[k] holds the variance of cv[k]
+    int use_vplane;        // 0 only for A/B measurements (environment SVGF_NO_VARIANCE_PLANE at svgf_create)
     float *nrm[2];
     int *gid[2];
     float *pos[2];
@@ -119,6 +122,7 @@ extern "C" int svgf_params_default(SvgfParams *p)
 static void free_all(svgf_ctx *c)
 {
     for (int k = 0; k < 4; k++) if (c->cv[k]) (void)hipFree(c->cv[k]);
+    for (int k = 0; k < 4; k++) if (c->vp[k]) (void)hipFree(c->vp[k]);
     for (int k = 0; k < 2; k++) {
         if (c->nrm[k]) (void)hipFree(c->nrm[k]);
         if (c->gid[k]) (void)hipFree(c->gid[k]);
@@ -142,6 +146,8 @@ static void free_all(svgf_ctx *c)
 static int zero_state(svgf_ctx *c)
 {
     for (int k = 0; k < 4; k++) HIPC(c, hipMemset(c->cv[k], 0, c->n * sizeof(float4)));
+    for (int k = 0; k < 4; k++) HIPC(c, hipMemset(c->vp[k], 0, (size_t)(c->W + 2) * (c->H + 2) * sizeof(float)));
+    c->vp_valid = 0;
     for (int k = 0; k < 2; k++) {
         HIPC(c, hipMemset(c->nrm[k], 0, c->n * 3 * sizeof(float)));
         HIPC(c, hipMemset(c->gid[k], 0, c->n * sizeof(int)));
@@ -178,8 +184,10 @@ extern "C" int svgf_create(int device, int width, int height, svgf_ctx **out)
     memset(c, 0, sizeof(*c));
     c->device = device; c->W = width; c->H = height; c->n = (size_t)width * height;
     for (int k = 0; k < 16; k++) c->view_prev[k] = (k % 5 == 0) ? 1.0f : 0.0f;
+    c->use_vplane = getenv("SVGF_NO_VARIANCE_PLANE") ? 0 : 1;
     bool ok = true;
     for (int k = 0; k < 4 && ok; k++) ok = hipMalloc((void **)&c->cv[k], c->n * sizeof(float4)) == hipSuccess;
+    for (int k = 0; k < 4 && ok; k++) ok = hipMalloc((void **)&c->vp[k], (size_t)(width + 2) * (height + 2) * sizeof(float)) == hipSuccess;
     for (int k = 0; k < 2 && ok; k++) {
         ok = ok && hipMalloc((void **)&c->nrm[k], c->n * 3 * sizeof(float)) == hipSuccess;
         ok = ok && hipMalloc((void **)&c->gid[k], c->n * sizeof(int)) == hipSuccess;
@@ -366,6 +374,19 @@ extern "C" int svgf_denoise(svgf_ctx *c, void *out_rgb_dev, const void *in_rgb_d
         snprintf(c->err, sizeof(c->err), "svgf_denoise: kernel_variant %d unknown", p->kernel_variant);
         return SVGF_ERR_INVALID_ARG;
     }
+    // every level is validated before anything is enqueued or any context state changes: a failure half-way through the
+    // cascade would leave the colour history of this frame next to the G-buffer / moments of the previous one
+    if (p->kernel_variant == 2 && p->spatial_enable && p->right_view_option != 1 && p->right_view_option != 2) {
+        for (int level = 1; level <= p->atrous_nlevel; level++) {
+            AtrousArgs probe;
+            memset(&probe, 0, sizeof(probe));
+            probe.W = c->W; probe.H = c->H; probe.step = 1 << (p->paper_steps ? level - 1 : level);
+            if (!atrous_strip_supported(probe)) {
+                snprintf(c->err, sizeof(c->err), "svgf_denoise: strip kernel does not support %dx%d step %d", c->W, c->H, probe.step);
+                return SVGF_ERR_UNSUPPORTED;
+            }
+        }
+    }
     HIPC(c, hipSetDevice(c->device));
     hipStream_t s = (hipStream_t)stream;
     float *out = (float *)out_rgb_dev;
@@ -419,6 +440,7 @@ extern "C" int svgf_denoise(svgf_ctx *c, void *out_rgb_dev, const void *in_rgb_d
         } else {
             LAUNCH_T(SVGF_KERNEL_PREPARE, launch_prepare(in, g, c->cv[acc], c->nrm[gnew], c->gid[gnew], c->pos[gnew], c->W, c->H, ts));
         }
+        c->vp_valid &= ~(1u << acc);     // the temporal / prepare pass writes no variance plane: the first level gathers cv.w
 #undef LAUNCH_T
     }
     c->acc = acc;
@@ -465,21 +487,32 @@ extern "C" int svgf_denoise(svgf_ctx *c, void *out_rgb_dev, const void *in_rgb_d
             a.sigma_c = p->sigma_l; a.sigma_n = p->sigma_n; a.sigma_x = p->sigma_x;
             a.blur_variance = p->blur_variance ? 1 : 0;
             a.modulate = (last && p->sepcolor && p->addcolor) ? 1 : 0;
+            a.var = nullptr; a.var_dst = nullptr;
             bool strip = false, lattice = false;
             if (p->kernel_variant != 1) {
                 strip = atrous_strip_supported(a);
                 lattice = !strip && p->kernel_variant != 2 && atrous_lattice_supported(a);     // steps 64, 128, ...
-                if (!strip && p->kernel_variant == 2) {
-                    snprintf(c->err, sizeof(c->err), "svgf_denoise: strip kernel does not support %dx%d step %d", c->W, c->H, a.step);
-                    return SVGF_ERR_UNSUPPORTED;
-                }
             }
-            if (strip && p->kernel_variant == 3 && atrous_share_supported(a)) LAUNCH(SVGF_KERNEL_ATROUS, launch_atrous_share(a, s));
-            else if (strip && atrous_lane_supported(a) && (p->kernel_variant == 4 || (p->kernel_variant == 0 && lane_pays(c->W))))
-                LAUNCH(SVGF_KERNEL_ATROUS, launch_atrous_lane(a, s));      // steps 2, 4, 8: symmetric terms evaluated once
-            else if (strip)   LAUNCH(SVGF_KERNEL_ATROUS, launch_atrous_strip(a, s));
-            else if (lattice) LAUNCH(SVGF_KERNEL_ATROUS, launch_atrous_lattice(a, s));
-            else              LAUNCH(SVGF_KERNEL_ATROUS, launch_atrous_gather(a, s));
+            enum { K_SHARE, K_LANE, K_STRIP, K_LATTICE, K_GATHER } which;
+            if (strip && p->kernel_variant == 3 && atrous_share_supported(a)) which = K_SHARE;
+            else if (strip && atrous_lane_supported(a) && (p->kernel_variant == 4 || (p->kernel_variant == 0 && lane_pays(c->W)))) which = K_LANE;
+            else if (strip) which = K_STRIP;
+            else if (lattice) which = K_LATTICE;
+            else which = K_GATHER;
+            // the lane and strip kernels stage their 3x3 pre-blur rows from the source's 4-byte variance plane when the
+            // producer wrote one (temporal / prepare pass, or a lane / strip level), and write their own next to dst
+            if ((which == K_LANE || which == K_STRIP) && c->use_vplane) {
+                if ((c->vp_valid >> src) & 1u) a.var = c->vp[src];
+                if (dst >= 0 && !last) a.var_dst = c->vp[dst];
+            }
+            if (dst >= 0) { if (a.var_dst) c->vp_valid |= 1u << dst; else c->vp_valid &= ~(1u << dst); }
+            switch (which) {
+            case K_SHARE:   LAUNCH(SVGF_KERNEL_ATROUS, launch_atrous_share(a, s)); break;
+            case K_LANE:    LAUNCH(SVGF_KERNEL_ATROUS, launch_atrous_lane(a, s)); break;     // steps 2, 4, 8: symmetric terms evaluated once
+            case K_STRIP:   LAUNCH(SVGF_KERNEL_ATROUS, launch_atrous_strip(a, s)); break;
+            case K_LATTICE: LAUNCH(SVGF_KERNEL_ATROUS, launch_atrous_lattice(a, s)); break;
+            default:        LAUNCH(SVGF_KERNEL_ATROUS, launch_atrous_gather(a, s)); break;
+            }
             if (hist_final && dst >= 0) c->inflight_mask |= 1u << dst;   // written after the history is final
             if (keep) {
                 c->hist = dst;

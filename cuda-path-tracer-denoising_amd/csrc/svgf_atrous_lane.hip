@@ -115,7 +115,7 @@ __global__ __launch_bounds__(NT) void k_atrous_lane(AtrousArgs a, LaneGeom gm)
     // control flow first needs them — LaneGeom for the work-item decode, W/H behind the first early return, the plane
     // pointers behind the second — three dependent scalar-memory round trips (several hundred cycles each, cold) in
     // front of the first global load of the prologue.
-    asm volatile("" :: "s"(a.src), "s"(a.dst), "s"(a.out_rgb), "s"(a.nrm), "s"(a.pos), "s"(a.gbuf), "s"(a.W), "s"(a.H),
+    asm volatile("" :: "s"(a.src), "s"(a.dst), "s"(a.out_rgb), "s"(a.nrm), "s"(a.pos), "s"(a.gbuf), "s"(a.var), "s"(a.var_dst), "s"(a.W), "s"(a.H),
                  "s"(a.sigma_c), "s"(a.blur_variance), "s"(a.modulate), "s"(gm.n_strips), "s"(gm.n_segs), "s"(gm.seg_rows),
                  "s"(gm.n_groups), "s"(gm.kn), "s"(gm.kx));
 
@@ -134,6 +134,12 @@ __global__ __launch_bounds__(NT) void k_atrous_lane(AtrousArgs a, LaneGeom gm)
     if (b0 >= b1) return;
     const int x0 = strip * TXO;
     const int tid = threadIdx.x;
+    // where the pre-blur rows come from: the zero-margined 4-byte variance plane of the source ((W+2) x (H+2), written by
+    // the producer next to its colour plane) when there is one — contiguous dwords — else the .w of the 16-byte colour
+    // texels (4 useful bytes per 16 fetched).  vbase points at pixel (0, 0).
+    const bool vplane = (a.var != nullptr);
+    const char *vbase = vplane ? reinterpret_cast<const char *>(a.var) + ((size_t)W + 3) * 4 : reinterpret_cast<const char *>(a.src) + 12;
+    const unsigned vxs = vplane ? 4u : 16u, vys = vplane ? (unsigned)(W + 2) * 4u : (unsigned)W * 16u;
     if (tid == 0) *nan_seen = 0;
     float sigma_c = a.sigma_c;
     asm volatile("" : "+s"(sigma_c));
@@ -219,7 +225,7 @@ __global__ __launch_bounds__(NT) void k_atrous_lane(AtrousArgs a, LaneGeom gm)
                 const int d = e / BW, xb = e - d * BW;
                 const int y = phase + (bo << LOG2S) + (d ? 1 : -1);
                 const int xs = x0 - 1 + xb;
-                if (y >= 0 && y < H && xs >= 0 && xs < W && bo < b1) v[m] = a.src[(unsigned)y * (unsigned)W + (unsigned)xs].w;
+                if (y >= 0 && y < H && xs >= 0 && xs < W && bo < b1) v[m] = *reinterpret_cast<const float *>(vbase + (unsigned)y * vys + (unsigned)xs * vxs);
             }
         }
     };
@@ -263,7 +269,7 @@ __global__ __launch_bounds__(NT) void k_atrous_lane(AtrousArgs a, LaneGeom gm)
                 const int xs = x0 - 1 + xb;
                 b_d[m] = (d != 0);
                 b_lds[m] = (e < 2 * BW) ? (d * BLUR_ROW + bel_of(xb)) : -1;
-                b_voff[m] = (e < 2 * BW && xs >= 0 && xs < W) ? (xs * 16 + 12) : -1;
+                b_voff[m] = (e < 2 * BW && xs >= 0 && xs < W) ? (int)((unsigned)xs * vxs) : -1;
             }
         }
     };
@@ -287,10 +293,10 @@ __global__ __launch_bounds__(NT) void k_atrous_lane(AtrousArgs a, LaneGeom gm)
             }
             if (a.blur_variance) {
                 const int ym = phase + (bo << LOG2S) - 1, yp = ym + 2;
-                const unsigned rm = (unsigned)(min(max(ym, 0), H - 1) * W) * 16u, rp = (unsigned)(min(max(yp, 0), H - 1) * W) * 16u;
+                const unsigned rm = (unsigned)min(max(ym, 0), H - 1) * vys, rp = (unsigned)min(max(yp, 0), H - 1) * vys;
 #pragma unroll
                 for (int m = 0; m < MBL; m++)
-                    lbv[m] = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(a.src) + (b_d[m] ? rp : rm) + (unsigned)max(b_voff[m], 12));
+                    lbv[m] = *reinterpret_cast<const float *>(vbase + (b_d[m] ? rp : rm) + (unsigned)max(b_voff[m], 0));
             }
         }
     };
@@ -710,6 +716,7 @@ __global__ __launch_bounds__(NT) void k_atrous_lane(AtrousArgs a, LaneGeom gm)
                 o0 *= t[6] * t[9]; o1 *= t[7] * t[10]; o2 *= t[8] * t[11];
             }
             if (a.dst) a.dst[p] = make_float4(o0, o1, o2, ov);
+            if (a.var_dst) a.var_dst[(unsigned)(y + 1) * (unsigned)(W + 2) + (unsigned)(x + 1)] = ov;
             if (a.out_rgb) { float *o = a.out_rgb + 3u * p; o[0] = o0; o[1] = o1; o[2] = o2; }
         }
     };

@@ -169,7 +169,7 @@ __global__ __launch_bounds__(TX * ROWS + loader_threads(TX, ROWS)) void k_atrous
 
     // every kernel argument in one batch of s_loads at entry (see svgf_atrous_lane.hip: three dependent scalar-memory round
     // trips in front of the prologue's first global load otherwise)
-    asm volatile("" :: "s"(a.src), "s"(a.dst), "s"(a.out_rgb), "s"(a.nrm), "s"(a.pos), "s"(a.gbuf), "s"(a.W), "s"(a.H),
+    asm volatile("" :: "s"(a.src), "s"(a.dst), "s"(a.out_rgb), "s"(a.nrm), "s"(a.pos), "s"(a.gbuf), "s"(a.var), "s"(a.var_dst), "s"(a.W), "s"(a.H),
                  "s"(a.sigma_c), "s"(a.blur_variance), "s"(a.modulate), "s"(gm.n_strips), "s"(gm.n_segs), "s"(gm.seg_rows),
                  "s"(gm.n_groups), "s"(gm.kn), "s"(gm.kx));
 
@@ -189,6 +189,12 @@ __global__ __launch_bounds__(TX * ROWS + loader_threads(TX, ROWS)) void k_atrous
     const int x0 = strip * TX;
 
     const int tid = threadIdx.x;
+    // where the pre-blur rows come from: the zero-margined 4-byte variance plane of the source ((W+2) x (H+2), written by
+    // the producer next to its colour plane) when there is one — contiguous dwords — else the .w of the 16-byte colour
+    // texels (4 useful bytes per 16 fetched, the 1.55-1.65x over-fetch of steps 16/32).  vbase points at pixel (0, 0).
+    const bool vplane = (a.var != nullptr);
+    const char *vbase = vplane ? reinterpret_cast<const char *>(a.var) + ((size_t)W + 3) * 4 : reinterpret_cast<const char *>(a.src) + 12;
+    const unsigned vxs = vplane ? 4u : 16u, vys = vplane ? (unsigned)(W + 2) * 4u : (unsigned)W * 16u;
 
     if (tid == 0) *nan_seen = 0;
     // the one kernel argument only the compute waves use: fetch it now rather than behind the prologue barrier
@@ -265,7 +271,7 @@ __global__ __launch_bounds__(TX * ROWS + loader_threads(TX, ROWS)) void k_atrous
                 const int d = rem / BW, xi = rem - d * BW;
                 const int y = phase + ((bo_first + rr) << LOG2S) + (d ? 1 : -1);
                 const int xs = x0 - 1 + xi;
-                if (y >= 0 && y < H && xs >= 0 && xs < W && bo_first + rr < b1) v[m] = a.src[(unsigned)y * (unsigned)W + (unsigned)xs].w;
+                if (y >= 0 && y < H && xs >= 0 && xs < W && bo_first + rr < b1) v[m] = *reinterpret_cast<const float *>(vbase + (unsigned)y * vys + (unsigned)xs * vxs);
             }
         }
     };
@@ -320,7 +326,7 @@ __global__ __launch_bounds__(TX * ROWS + loader_threads(TX, ROWS)) void k_atrous
             for (int t = 0; t < NBT; t++) {
                 const int xs = x0 - 1 + llane + t * kLoaderGroup;
                 b_ok[t] = (xs >= 0 && xs < W);
-                b_voff[t] = min(max(xs, 0), W - 1) * 16 + 12;
+                b_voff[t] = (int)((unsigned)min(max(xs, 0), W - 1) * vxs);
             }
         }
     };
@@ -332,7 +338,7 @@ __global__ __launch_bounds__(TX * ROWS + loader_threads(TX, ROWS)) void k_atrous
         const int y = phase + ((bcj + rr) << LOG2S) + ((c & 1) ? 1 : -1);
         const int xs = x0 - 1 + xi;
         ok = (llane < 2 * NBC) && y >= 0 && y < H && xs >= 0 && xs < W && (bcj + rr < b1);
-        q = (unsigned)min(max(y, 0), H - 1) * (unsigned)W + (unsigned)min(max(xs, 0), W - 1);
+        q = (unsigned)min(max(y, 0), H - 1) * vys + (unsigned)min(max(xs, 0), W - 1) * vxs;      // byte offset from vbase
     };
     // new rows of iteration j: lattice rows b0 + j*ROWS + 2 .. +ROWS-1 (+ROWS); its output rows start at b0 + j*ROWS
     auto loader_issue = [&](int j) {
@@ -363,13 +369,13 @@ __global__ __launch_bounds__(TX * ROWS + loader_threads(TX, ROWS)) void k_atrous
 #pragma unroll
                 for (int c = 0; c < NBC; c++) {
                     const int y = phase + ((bcj + (c >> 1)) << LOG2S) + ((c & 1) ? 1 : -1);              // wave-uniform
-                    const char *rowp = reinterpret_cast<const char *>(a.src) + (size_t)(min(max(y, 0), H - 1) * W) * 16u;
+                    const char *rowp = vbase + (size_t)min(max(y, 0), H - 1) * vys;
 #pragma unroll
                     for (int t = 0; t < NBT; t++) lbv[c * NBT + t] = *reinterpret_cast<const float *>(rowp + b_voff[t]);
                 }
                 int c, xi; bool ok; unsigned q;
                 blur_extra_coords(bcj, c, xi, ok, q);
-                lbv[NBC * NBT] = a.src[q].w;
+                lbv[NBC * NBT] = *reinterpret_cast<const float *>(vbase + q);
             }
         }
     };
@@ -624,6 +630,7 @@ __global__ __launch_bounds__(TX * ROWS + loader_threads(TX, ROWS)) void k_atrous
                 o0 *= t[6] * t[9]; o1 *= t[7] * t[10]; o2 *= t[8] * t[11];
             }
             if (a.dst) a.dst[p] = make_float4(o0, o1, o2, ov);
+            if (a.var_dst) a.var_dst[(unsigned)(y + 1) * (unsigned)(W + 2) + (unsigned)(x + 1)] = ov;
             if (a.out_rgb) { float *o = a.out_rgb + 3u * p; o[0] = o0; o[1] = o1; o[2] = o2; }
         }
         stamp(5);

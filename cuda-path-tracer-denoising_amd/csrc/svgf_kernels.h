@@ -24,6 +24,8 @@ struct AtrousArgs {
     float sigma_c, sigma_n, sigma_x;
     int blur_variance;
     int modulate;
+    const float *var;         // optional 4-B/px variance plane holding src[].w (pre-blur neighbourhood reads), may be null
+    float *var_dst;           // optional 4-B/px variance plane written next to dst, may be null
 };
 
 struct TemporalArgs {

@@ -116,7 +116,9 @@ def build_cases(pkg):
     fr169, cams169 = synth_frames(pkg, 128, 72, 1, seed=12, moving=False)
     cases.append(dict(name="atrous_synth128x72_n5", W=128, H=72, frames=fr169, cams=cams169, race_free=True,
                       calls=[(1, 0, default_params(spatial_enable=1, atrous_nlevel=5))], note="16:9"))
-    for (W, H, seed) in ((37, 23, 5), (5, 3, 6), (1, 1, 7), (64, 9, 8)):
+    # 470x11: the library's auto selection takes the lane-marching kernel (480-column strips fit); 1280x9: it takes the
+    # strip kernel for every step (svgf_api.hip lane_pays)
+    for (W, H, seed) in ((37, 23, 5), (5, 3, 6), (1, 1, 7), (64, 9, 8), (470, 11, 15), (1280, 9, 16)):
         c, g = S.random_frame(W, H, seed=seed)
         cam0 = S.camera_for_frame(0, False)
         cam0 = {k: np.asarray(cam0[k], dtype=np.float32) for k in ("right", "up", "view", "position")}
@@ -188,6 +190,7 @@ def main():
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "ref_gpu"))
     ap.add_argument("--compare", action="store_true", help="also run the CPU oracle and the HIP library")
     ap.add_argument("--time-1080p", action="store_true", help="time the reference's denoise() at 1920x1080")
+    ap.add_argument("--only", default="", help="comma-separated case names: generate just these")
     a = ap.parse_args()
     pkg = ge.load_package()
     if not os.path.exists(REF_BIN):
@@ -196,6 +199,8 @@ def main():
     work = os.path.join("/tmp", "svgf_ref_work")
     report = {}
     cases = build_cases(pkg)
+    if a.only:
+        cases = [c for c in cases if c["name"] in a.only.split(",")]
     orc = ge.load_oracle() if a.compare else None
     for cs in cases:
         W, H = cs["W"], cs["H"]

@@ -7,7 +7,8 @@ Primary goldens are from the -ffp-contract=off build of the reference: arithmeti
   * full SVGF sequences, which the reference races on (in-place variance): the snapshot oracle still agrees to
     2e-6 at these sizes because all workgroups of the reference kernel are co-resident on a 256-CU GPU.
 Secondary goldens (default hipcc flags, FMA contraction on) bound what a compiler's contraction freedom changes:
->= 97 % of channel values within 1e-4 (1-ulp differences flip floor()/(int) decisions on a few pixels).
+>= 99.2 % of channel values within 1e-4 (1-ulp differences flip floor()/(int) decisions on a few pixels; measured
+99.29 % .. 100 %, profiles/r01_reference_on_mi355x_goldens.log).
 """
 import numpy as np
 import pytest
@@ -46,7 +47,7 @@ def test_oracle_vs_reference_default_flags(pkg, orc, name):
         got = replay(pkg, o, z, tag)
         o.free()
         e = relerr(got, z[f"ref_out_{tag}"])
-        assert (e <= 1e-4).mean() >= 0.97, f"{name}:{tag} only {(e <= 1e-4).mean():.4f} within 1e-4"
+        assert (e <= 1e-4).mean() >= 0.992, f"{name}:{tag} only {(e <= 1e-4).mean():.4f} within 1e-4"
 
 
 def test_inplace_mode_is_equal_where_variance_is_uniform(pkg, orc):

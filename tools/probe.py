@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--nlevel", type=int, default=5)
     ap.add_argument("--check", action="store_true", help="compare outputs of the variants frame by frame")
     ap.add_argument("--overlap", type=int, default=0, help="SvgfParams.inputs_ready")
+    ap.add_argument("--blur", type=int, default=1, help="SvgfParams.blur_variance")
     a = ap.parse_args()
     import torch
     pkg = ge.load_package()
@@ -41,7 +42,7 @@ def main():
     results = {}
     for v in [int(x) for x in a.variants.split(",")]:
         d = pkg.Denoiser(W, H, 0)
-        p = pkg.reference_defaults().set(temporal_enable=1, spatial_enable=1, atrous_nlevel=a.nlevel, kernel_variant=v, inputs_ready=a.overlap)
+        p = pkg.reference_defaults().set(temporal_enable=1, spatial_enable=1, atrous_nlevel=a.nlevel, kernel_variant=v, inputs_ready=a.overlap, blur_variance=a.blur)
         d.profile_enable(a.frames)
         outs = []
         for f in range(a.frames):
