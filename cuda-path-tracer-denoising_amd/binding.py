@@ -49,7 +49,8 @@ class SvgfParams(C.Structure):
                 ("sigma_x", C.c_float), ("sigma_n", C.c_float), ("atrous_nlevel", C.c_int),
                 ("history_level", C.c_int), ("sepcolor", C.c_int), ("addcolor", C.c_int),
                 ("right_view_option", C.c_int), ("kernel_variant", C.c_int), ("inputs_ready", C.c_int),
-                ("reproj_scale", C.c_float * 2), ("paper_steps", C.c_int)]
+                ("reproj_scale", C.c_float * 2), ("paper_steps", C.c_int), ("reproj_position_tol", C.c_float),
+                ("spatial_variance_frames", C.c_int)]
 
     def set(self, **kw):
         for k, v in kw.items():

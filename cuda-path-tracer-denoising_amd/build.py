@@ -12,7 +12,7 @@ LIB = os.path.join(_HERE, "libsvgf_hip.so")
 ORACLE_DIR = os.path.join(ROOT, "oracle")
 ORACLE_LIB = os.path.join(ORACLE_DIR, "libsvgf_oracle.so")
 
-HIP_SOURCES = ["svgf_api.hip", "svgf_kernels.hip", "svgf_atrous_strip.hip", "svgf_atrous_share.hip", "svgf_atrous_lane.hip", "svgf_atrous_lattice.hip", "svgf_synth.hip", "svgf_scene.hip", "svgf_display.hip"]
+HIP_SOURCES = ["svgf_api.hip", "svgf_kernels.hip", "svgf_atrous_strip.hip", "svgf_atrous_lane.hip", "svgf_atrous_lattice.hip", "svgf_synth.hip", "svgf_scene.hip", "svgf_display.hip"]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-function"]
 
 

@@ -145,8 +145,8 @@ static void free_all(svgf_ctx *c)
 
 static int zero_state(svgf_ctx *c)
 {
-    for (int k = 0; k < 4; k++) HIPC(c, hipMemset(c->cv[k], 0, c->n * sizeof(float4)));
-    for (int k = 0; k < 4; k++) HIPC(c, hipMemset(c->vp[k], 0, (size_t)(c->W + 2) * (c->H + 2) * sizeof(float)));
+    for (int k = 0; k < 4; k++) if (c->cv[k]) HIPC(c, hipMemset(c->cv[k], 0, c->n * sizeof(float4)));
+    for (int k = 0; k < 4; k++) if (c->vp[k]) HIPC(c, hipMemset(c->vp[k], 0, (size_t)(c->W + 2) * (c->H + 2) * sizeof(float)));
     c->vp_valid = 0;
     for (int k = 0; k < 2; k++) {
         HIPC(c, hipMemset(c->nrm[k], 0, c->n * 3 * sizeof(float)));
@@ -175,8 +175,9 @@ extern "C" int svgf_create(int device, int width, int height, svgf_ctx **out)
                  ndev, hipGetErrorString(e));
         return SVGF_ERR_NO_DEVICE;
     }
-    if ((e = hipSetDevice(device)) != hipSuccess) {
-        snprintf(g_create_err, sizeof(g_create_err), "hipSetDevice(%d): %s", device, hipGetErrorString(e));
+    SvgfDeviceGuard dev_guard(device);
+    if (!dev_guard.ok) {
+        snprintf(g_create_err, sizeof(g_create_err), "hipSetDevice(%d) failed", device);
         return SVGF_ERR_NO_DEVICE;
     }
     svgf_ctx *c = new (std::nothrow) svgf_ctx();
@@ -186,8 +187,10 @@ extern "C" int svgf_create(int device, int width, int height, svgf_ctx **out)
     for (int k = 0; k < 16; k++) c->view_prev[k] = (k % 5 == 0) ? 1.0f : 0.0f;
     c->use_vplane = getenv("SVGF_NO_VARIANCE_PLANE") ? 0 : 1;
     bool ok = true;
-    for (int k = 0; k < 4 && ok; k++) ok = hipMalloc((void **)&c->cv[k], c->n * sizeof(float4)) == hipSuccess;
-    for (int k = 0; k < 4 && ok; k++) ok = hipMalloc((void **)&c->vp[k], (size_t)(width + 2) * (height + 2) * sizeof(float)) == hipSuccess;
+    // three colour planes serve the ordered path (history, source, destination); the fourth one, the side stream and its
+    // events belong to the cross-frame overlap and are created when a frame first asks for it (ensure_overlap_resources)
+    for (int k = 0; k < 3 && ok; k++) ok = hipMalloc((void **)&c->cv[k], c->n * sizeof(float4)) == hipSuccess;
+    for (int k = 0; k < 3 && ok; k++) ok = hipMalloc((void **)&c->vp[k], (size_t)(width + 2) * (height + 2) * sizeof(float)) == hipSuccess;
     for (int k = 0; k < 2 && ok; k++) {
         ok = ok && hipMalloc((void **)&c->nrm[k], c->n * 3 * sizeof(float)) == hipSuccess;
         ok = ok && hipMalloc((void **)&c->gid[k], c->n * sizeof(int)) == hipSuccess;
@@ -195,13 +198,6 @@ extern "C" int svgf_create(int device, int width, int height, svgf_ctx **out)
         ok = ok && hipMalloc((void **)&c->hlen[k], c->n * sizeof(int)) == hipSuccess;
         ok = ok && hipMalloc((void **)&c->pos[k], c->n * 3 * sizeof(float)) == hipSuccess;
     }
-    {
-        int lo = 0, hi = 0;   // the side stream carries the short, latency-sensitive temporal pass: highest priority
-        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-        ok = ok && hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, hi) == hipSuccess;
-    }
-    ok = ok && hipEventCreateWithFlags(&c->ev_hist, hipEventDisableTiming) == hipSuccess;
-    ok = ok && hipEventCreateWithFlags(&c->ev_temporal, hipEventDisableTiming) == hipSuccess;
     if (!ok) {
         snprintf(g_create_err, sizeof(g_create_err), "svgf_create: hipMalloc failed for %dx%d", width, height);
         free_all(c); delete c;
@@ -216,10 +212,30 @@ extern "C" int svgf_create(int device, int width, int height, svgf_ctx **out)
     return SVGF_OK;
 }
 
+// cross-frame overlap (SvgfParams::inputs_ready): a fourth colour plane, a high-priority side stream and two events
+static int ensure_overlap_resources(svgf_ctx *c)
+{
+    if (c->side) return SVGF_OK;
+    if (!c->cv[3]) {
+        HIPC(c, hipMalloc((void **)&c->cv[3], c->n * sizeof(float4)));
+        HIPC(c, hipMemset(c->cv[3], 0, c->n * sizeof(float4)));
+    }
+    if (!c->vp[3]) {
+        HIPC(c, hipMalloc((void **)&c->vp[3], (size_t)(c->W + 2) * (c->H + 2) * sizeof(float)));
+        HIPC(c, hipMemset(c->vp[3], 0, (size_t)(c->W + 2) * (c->H + 2) * sizeof(float)));
+    }
+    if (!c->ev_hist) HIPC(c, hipEventCreateWithFlags(&c->ev_hist, hipEventDisableTiming));
+    if (!c->ev_temporal) HIPC(c, hipEventCreateWithFlags(&c->ev_temporal, hipEventDisableTiming));
+    int lo = 0, hi = 0;   // the side stream carries the short, latency-sensitive temporal pass: highest priority
+    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+    HIPC(c, hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, hi));
+    return SVGF_OK;
+}
+
 extern "C" int svgf_destroy(svgf_ctx *c)
 {
     if (!c) return SVGF_OK;
-    (void)hipSetDevice(c->device);
+    SvgfDeviceGuard dev_guard(c->device);
     (void)hipDeviceSynchronize();
     free_all(c);
     delete c;
@@ -229,7 +245,8 @@ extern "C" int svgf_destroy(svgf_ctx *c)
 extern "C" int svgf_reset(svgf_ctx *c)
 {
     if (!c) return SVGF_ERR_INVALID_ARG;
-    HIPC(c, hipSetDevice(c->device));
+    SvgfDeviceGuard dev_guard(c->device);
+    if (!dev_guard.ok) { snprintf(c->err, sizeof(c->err), "hipSetDevice(%d) failed", c->device); return SVGF_ERR_HIP; }
     HIPC(c, hipDeviceSynchronize());
     return zero_state(c);
 }
@@ -237,7 +254,8 @@ extern "C" int svgf_reset(svgf_ctx *c)
 extern "C" int svgf_sync(svgf_ctx *c)
 {
     if (!c) return SVGF_ERR_INVALID_ARG;
-    HIPC(c, hipSetDevice(c->device));
+    SvgfDeviceGuard dev_guard(c->device);
+    if (!dev_guard.ok) { snprintf(c->err, sizeof(c->err), "hipSetDevice(%d) failed", c->device); return SVGF_ERR_HIP; }
     HIPC(c, hipDeviceSynchronize());
     return SVGF_OK;
 }
@@ -249,7 +267,8 @@ extern "C" int svgf_height(const svgf_ctx *c) { return c ? c->H : 0; }
 extern "C" int svgf_set_capture(svgf_ctx *c, int on)
 {
     if (!c) return SVGF_ERR_INVALID_ARG;
-    HIPC(c, hipSetDevice(c->device));
+    SvgfDeviceGuard dev_guard(c->device);
+    if (!dev_guard.ok) { snprintf(c->err, sizeof(c->err), "hipSetDevice(%d) failed", c->device); return SVGF_ERR_HIP; }
     if (on && !c->cv_capture) {
         HIPC(c, hipMalloc((void **)&c->cv_capture, c->n * sizeof(float4)));
         HIPC(c, hipMemset(c->cv_capture, 0, c->n * sizeof(float4)));
@@ -263,7 +282,8 @@ extern "C" int svgf_set_capture(svgf_ctx *c, int on)
 extern "C" int svgf_profile_enable(svgf_ctx *c, int nframes)
 {
     if (!c || nframes < 0) return SVGF_ERR_INVALID_ARG;
-    HIPC(c, hipSetDevice(c->device));
+    SvgfDeviceGuard dev_guard(c->device);
+    if (!dev_guard.ok) { snprintf(c->err, sizeof(c->err), "hipSetDevice(%d) failed", c->device); return SVGF_ERR_HIP; }
     if (c->ev) {
         for (long long k = 0; k < (long long)c->prof_frames * SVGF_MAX_KERNELS_PER_FRAME * 2; k++) (void)hipEventDestroy(c->ev[k]);
         free(c->ev); free(c->ev_kind); free(c->ev_n);
@@ -307,7 +327,8 @@ extern "C" long long svgf_profile_frames(const svgf_ctx *c) { return c ? c->prof
 extern "C" int svgf_profile_read(svgf_ctx *c, int slot, int max_entries, int *kinds, float *ms, int *n_out)
 {
     if (!c || !n_out || slot < 0 || slot >= c->prof_frames) return SVGF_ERR_INVALID_ARG;
-    HIPC(c, hipSetDevice(c->device));
+    SvgfDeviceGuard dev_guard(c->device);
+    if (!dev_guard.ok) { snprintf(c->err, sizeof(c->err), "hipSetDevice(%d) failed", c->device); return SVGF_ERR_HIP; }
     const int nk = c->ev_n[slot];
     int w = 0;
     for (int k = 0; k < nk && w < max_entries; k++, w++) {
@@ -370,8 +391,10 @@ extern "C" int svgf_denoise(svgf_ctx *c, void *out_rgb_dev, const void *in_rgb_d
         snprintf(c->err, sizeof(c->err), "svgf_denoise: atrous_nlevel %d outside 0..%d", p->atrous_nlevel, SVGF_MAX_LEVELS);
         return SVGF_ERR_INVALID_ARG;
     }
-    if (p->kernel_variant < 0 || p->kernel_variant > 4) {
-        snprintf(c->err, sizeof(c->err), "svgf_denoise: kernel_variant %d unknown", p->kernel_variant);
+    if (p->kernel_variant < 0 || p->kernel_variant > 4 || p->kernel_variant == 3) {
+        snprintf(c->err, sizeof(c->err), p->kernel_variant == 3
+                 ? "svgf_denoise: kernel_variant %d (experimental shared-weight kernel) is no longer part of the library, see tools/experiments/"
+                 : "svgf_denoise: kernel_variant %d unknown", p->kernel_variant);
         return SVGF_ERR_INVALID_ARG;
     }
     // every level is validated before anything is enqueued or any context state changes: a failure half-way through the
@@ -387,7 +410,8 @@ extern "C" int svgf_denoise(svgf_ctx *c, void *out_rgb_dev, const void *in_rgb_d
             }
         }
     }
-    HIPC(c, hipSetDevice(c->device));
+    SvgfDeviceGuard dev_guard(c->device);
+    if (!dev_guard.ok) { snprintf(c->err, sizeof(c->err), "hipSetDevice(%d) failed", c->device); return SVGF_ERR_HIP; }
     hipStream_t s = (hipStream_t)stream;
     float *out = (float *)out_rgb_dev;
     const float *in = (const float *)in_rgb_dev;
@@ -411,8 +435,13 @@ extern "C" int svgf_denoise(svgf_ctx *c, void *out_rgb_dev, const void *in_rgb_d
     //    Only the temporal pass is worth a second stream: the constant-variance fill of the non-temporal mode is a
     //    few microseconds, less than the cross-stream event hand-off costs.
     const bool overlap = (p->inputs_ready != 0) && (p->temporal_enable != 0);
+    if (overlap) { const int rc = ensure_overlap_resources(c); if (rc != SVGF_OK) return rc; }
+    const int ncv = c->cv[3] ? 4 : 3;
+    // planes the previous frame's trailing levels still write matter only when this frame's temporal pass may run beside
+    // them (side stream); on the ordered path the stream order protects them
+    const unsigned busy = overlap ? c->inflight_mask : 0u;
     int acc = -1;
-    for (int k = 0; k < 4; k++) if (k != c->hist && !((c->inflight_mask >> k) & 1u)) { acc = k; break; }
+    for (int k = 0; k < ncv; k++) if (k != c->hist && !((busy >> k) & 1u)) { acc = k; break; }
     if (acc < 0) { snprintf(c->err, sizeof(c->err), "svgf_denoise: internal error, no free colour plane"); return SVGF_ERR_HIP; }
     const int gnew = 1 - c->gcur;
     hipStream_t ts = overlap ? c->side : s;
@@ -436,7 +465,11 @@ extern "C" int svgf_denoise(svgf_ctx *c, void *out_rgb_dev, const void *in_rgb_d
             memcpy(t.M, c->view_prev, sizeof(t.M));
             t.W = c->W; t.H = c->H; t.color_alpha_min = p->color_alpha; t.moment_alpha_min = p->moment_alpha;
             t.reproj_sx = p->reproj_scale[0]; t.reproj_sy = p->reproj_scale[1];
+            t.pos_prev = c->pos[c->gcur]; t.pos_tol = p->reproj_position_tol;
             LAUNCH_T(SVGF_KERNEL_TEMPORAL, launch_temporal(t, ts, overlap && c->ev_hist_valid));
+            if (p->spatial_variance_frames > 0)      // f4 extension: spatial variance estimate for short histories
+                HIPC(c, launch_spatial_variance(c->cv[acc], c->mom[1 - c->cur], c->hlen[1 - c->cur], c->nrm[gnew], c->gid[gnew],
+                                                c->W, c->H, p->spatial_variance_frames, ts));
         } else {
             LAUNCH_T(SVGF_KERNEL_PREPARE, launch_prepare(in, g, c->cv[acc], c->nrm[gnew], c->gid[gnew], c->pos[gnew], c->W, c->H, ts));
         }
@@ -454,6 +487,7 @@ extern "C" int svgf_denoise(svgf_ctx *c, void *out_rgb_dev, const void *in_rgb_d
     bool hist_final = false;         // has the kernel that produces next frame's colour history been enqueued?
     auto mark_hist_final = [&]() -> bool {
         hist_final = true;
+        if (!c->ev_hist) return true;                 // overlap never used on this context: nobody waits for the event
         if (hipEventRecord(c->ev_hist, s) != hipSuccess) return false;
         c->ev_hist_valid = 1;
         return true;
@@ -461,7 +495,11 @@ extern "C" int svgf_denoise(svgf_ctx *c, void *out_rgb_dev, const void *in_rgb_d
 
     // 2) debug views, pass-through or the a-trous cascade (:373-394)
     const bool cascade = !(p->right_view_option == 1 || p->right_view_option == 2 || p->atrous_nlevel == 0 || !p->spatial_enable);
-    if (!cascade || p->history_level < 1 || p->history_level > p->atrous_nlevel) {
+    // When no a-trous level feeds the history, the history (colour, moments, lengths) is final after the temporal pass —
+    // but the next frame's temporal pass, which waits on ev_hist only, REWRITES the planes the debug / copy kernels below
+    // read (hlen[cur] becomes next frame's hlen_upd): the event is recorded behind those kernels, not in front of them.
+    const bool hist_final_early = !cascade || p->history_level < 1 || p->history_level > p->atrous_nlevel;
+    if (hist_final_early && cascade) {
         if (!mark_hist_final()) { snprintf(c->err, sizeof(c->err), "hipEventRecord failed"); return SVGF_ERR_HIP; }
     }
     if (p->right_view_option == 1) {
@@ -477,7 +515,7 @@ extern "C" int svgf_denoise(svgf_ctx *c, void *out_rgb_dev, const void *in_rgb_d
             const bool keep = (level == p->history_level);      // this level's output becomes the colour history (:391)
             int dst = -1;
             if (!last || keep) {
-                for (int k = 0; k < 4; k++) if (k != src && k != c->hist) { dst = k; break; }
+                for (int k = 0; k < ncv; k++) if (k != src && k != c->hist) { dst = k; break; }
             }
             AtrousArgs a;
             a.src = c->cv[src]; a.dst = dst >= 0 ? c->cv[dst] : nullptr; a.out_rgb = last ? out : nullptr;
@@ -493,21 +531,24 @@ extern "C" int svgf_denoise(svgf_ctx *c, void *out_rgb_dev, const void *in_rgb_d
                 strip = atrous_strip_supported(a);
                 lattice = !strip && p->kernel_variant != 2 && atrous_lattice_supported(a);     // steps 64, 128, ...
             }
-            enum { K_SHARE, K_LANE, K_STRIP, K_LATTICE, K_GATHER } which;
-            if (strip && p->kernel_variant == 3 && atrous_share_supported(a)) which = K_SHARE;
-            else if (strip && atrous_lane_supported(a) && (p->kernel_variant == 4 || (p->kernel_variant == 0 && lane_pays(c->W)))) which = K_LANE;
+            enum { K_LANE, K_STRIP, K_LATTICE, K_GATHER } which;
+            if (strip && atrous_lane_supported(a) && (p->kernel_variant == 4 || (p->kernel_variant == 0 && lane_pays(c->W)))) which = K_LANE;
             else if (strip) which = K_STRIP;
             else if (lattice) which = K_LATTICE;
             else which = K_GATHER;
-            // the lane and strip kernels stage their 3x3 pre-blur rows from the source's 4-byte variance plane when the
-            // producer wrote one (temporal / prepare pass, or a lane / strip level), and write their own next to dst
+            // Pre-blur rows (y-1, y+1 of the full-resolution image) of the lane / strip kernels.  At steps >= 16 they are
+            // read as 4-byte gathers out of 16-byte colour texels whose lines nobody else on the XCD touches (PMC: 75.6 /
+            // 72.6 B/px fetched against 40 algorithmic); there the kernels read them from a zero-margined 4-byte variance plane
+            // that the producer level writes next to its colour plane (51.3 / 48.8 B/px, +4 B/px written).  At steps 2-8
+            // the neighbouring rows are the sibling y-phases' own rows, already in L2: a plane would ADD 8 B/px (measured,
+            // profiles/r02_pmc_hbm.txt), so those levels keep reading colour.w and only the level feeding a step-16 level
+            // writes the plane.
             if ((which == K_LANE || which == K_STRIP) && c->use_vplane) {
-                if ((c->vp_valid >> src) & 1u) a.var = c->vp[src];
-                if (dst >= 0 && !last) a.var_dst = c->vp[dst];
+                if (a.step >= 16 && ((c->vp_valid >> src) & 1u)) a.var = c->vp[src];
+                if (dst >= 0 && !last && a.step >= 8) a.var_dst = c->vp[dst];
             }
             if (dst >= 0) { if (a.var_dst) c->vp_valid |= 1u << dst; else c->vp_valid &= ~(1u << dst); }
             switch (which) {
-            case K_SHARE:   LAUNCH(SVGF_KERNEL_ATROUS, launch_atrous_share(a, s)); break;
             case K_LANE:    LAUNCH(SVGF_KERNEL_ATROUS, launch_atrous_lane(a, s)); break;     // steps 2, 4, 8: symmetric terms evaluated once
             case K_STRIP:   LAUNCH(SVGF_KERNEL_ATROUS, launch_atrous_strip(a, s)); break;
             case K_LATTICE: LAUNCH(SVGF_KERNEL_ATROUS, launch_atrous_lattice(a, s)); break;
@@ -520,6 +561,10 @@ extern "C" int svgf_denoise(svgf_ctx *c, void *out_rgb_dev, const void *in_rgb_d
             }
             src = dst;
         }
+    }
+
+    if (!cascade) {
+        if (!mark_hist_final()) { snprintf(c->err, sizeof(c->err), "hipEventRecord failed"); return SVGF_ERR_HIP; }
     }
 
     // 3) history rotation (:396-399): planes swap roles instead of being copied
@@ -539,7 +584,8 @@ extern "C" int svgf_denoise_host(svgf_ctx *c, float *out_rgb_host, const float *
         snprintf(c->err, sizeof(c->err), "svgf_denoise_host: null argument");
         return SVGF_ERR_INVALID_ARG;
     }
-    HIPC(c, hipSetDevice(c->device));
+    SvgfDeviceGuard dev_guard(c->device);
+    if (!dev_guard.ok) { snprintf(c->err, sizeof(c->err), "hipSetDevice(%d) failed", c->device); return SVGF_ERR_HIP; }
     if (!c->st_in) HIPC(c, hipMalloc((void **)&c->st_in, c->n * 3 * sizeof(float)));
     if (!c->st_out) HIPC(c, hipMalloc((void **)&c->st_out, c->n * 3 * sizeof(float)));
     if (!c->st_g) HIPC(c, hipMalloc((void **)&c->st_g, c->n * sizeof(SvgfGBufferTexel)));
@@ -557,7 +603,8 @@ extern "C" int svgf_denoise_host(svgf_ctx *c, float *out_rgb_host, const float *
 extern "C" int svgf_read_state(svgf_ctx *c, int which, void *host_dst, unsigned long long host_bytes)
 {
     if (!c || !host_dst) return SVGF_ERR_INVALID_ARG;
-    HIPC(c, hipSetDevice(c->device));
+    SvgfDeviceGuard dev_guard(c->device);
+    if (!dev_guard.ok) { snprintf(c->err, sizeof(c->err), "hipSetDevice(%d) failed", c->device); return SVGF_ERR_HIP; }
     HIPC(c, hipDeviceSynchronize());
     const size_t n = c->n;
     auto need = [&](size_t b) -> bool {

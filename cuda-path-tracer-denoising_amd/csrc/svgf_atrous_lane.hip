@@ -141,6 +141,7 @@ __global__ __launch_bounds__(NT) void k_atrous_lane(AtrousArgs a, LaneGeom gm)
     const char *vbase = vplane ? reinterpret_cast<const char *>(a.var) + ((size_t)W + 3) * 4 : reinterpret_cast<const char *>(a.src) + 12;
     const unsigned vxs = vplane ? 4u : 16u, vys = vplane ? (unsigned)(W + 2) * 4u : (unsigned)W * 16u;
     if (tid == 0) *nan_seen = 0;
+    __syncthreads();           // the flag is initialised before any wave's prologue can raise it
     float sigma_c = a.sigma_c;
     asm volatile("" : "+s"(sigma_c));
     int dbg_it = 0;
@@ -737,23 +738,13 @@ hipError_t launch_lane_cfg(const AtrousArgs &a, hipStream_t s)
 {
     constexpr int S = 1 << LOG2S, M = LOUT * (NWC / S) + 4, MP = (M * 12 % 64 == 0) ? M + 1 : M, BM = (BW + S - 1) / S;
     const size_t lds = (size_t)R * S * MP * PXB + (size_t)2 * 2 * S * BM * 4 + 16;
-    static bool attr_done[64] = {};
+    static SvgfLaunchCache cache;
     int dev_id = 0;
-    (void)hipGetDevice(&dev_id);
-    if (dev_id < 0 || dev_id >= 64) dev_id = 0;
-    if (!attr_done[dev_id]) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_atrous_lane<LOG2S, HASVAR>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        attr_done[dev_id] = true;
-    }
+    if (hipError_t e = cache.init(reinterpret_cast<const void *>(&k_atrous_lane<LOG2S, HASVAR>), (int)lds, &dev_id); e != hipSuccess) return e;
+    const int n_cu = cache.n_cu[dev_id];
     LaneGeom gm;
     gm.n_strips = (a.W + TXO - 1) / TXO;
     const int nb_max = (a.H + S - 1) / S;
-    static int n_cu = 0;
-    if (!n_cu) {
-        if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev_id) != hipSuccess || n_cu <= 0) n_cu = 256;
-    }
     // segment length: one workgroup per CU (LDS-bound); the busiest XCD sets the number of rounds (see the strip kernel)
     int best_L = nb_max;
     long best_cost = -1;

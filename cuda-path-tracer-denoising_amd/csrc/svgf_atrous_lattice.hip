@@ -262,17 +262,9 @@ bool geometry(const AtrousArgs &a, LatticeGeom &gm)
 template <bool HASVAR>
 hipError_t launch_cfg(const AtrousArgs &a, const LatticeGeom &gm, hipStream_t s)
 {
-    // per device: the opt-in to more than 64 KB of dynamic LDS is a per-device function attribute
-    static bool attr_done[64] = {};
+    static SvgfLaunchCache cache;
     int dev_id = 0;
-    (void)hipGetDevice(&dev_id);
-    if (dev_id < 0 || dev_id >= 64) dev_id = 0;
-    if (!attr_done[dev_id]) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_atrous_lattice<HASVAR>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBudget);
-        if (e != hipSuccess) return e;
-        attr_done[dev_id] = true;
-    }
+    if (hipError_t e = cache.init(reinterpret_cast<const void *>(&k_atrous_lattice<HASVAR>), kLdsBudget, &dev_id); e != hipSuccess) return e;
     const size_t lds = (size_t)(gm.pstride << gm.log2k) * (gm.band_rows + 4) * PXB;
     const unsigned nblocks = (((unsigned)a.step * (unsigned)a.step) >> gm.log2k) * (unsigned)gm.n_bands;
     hipLaunchKernelGGL(k_atrous_lattice<HASVAR>, dim3(nblocks), dim3(NT), lds, s, a, gm);

@@ -197,6 +197,7 @@ __global__ __launch_bounds__(TX * ROWS + loader_threads(TX, ROWS)) void k_atrous
     const unsigned vxs = vplane ? 4u : 16u, vys = vplane ? (unsigned)(W + 2) * 4u : (unsigned)W * 16u;
 
     if (tid == 0) *nan_seen = 0;
+    __syncthreads();           // the flag is initialised before any wave's prologue can raise it
     // the one kernel argument only the compute waves use: fetch it now rather than behind the prologue barrier
     // (an s_load from the kernarg segment that misses the scalar cache costs several hundred cycles)
     float sigma_c = a.sigma_c;
@@ -645,30 +646,16 @@ hipError_t launch_cfg(const AtrousArgs &a, hipStream_t s)
 {
     constexpr int S = 1 << LOG2S, RW = TX + 4 * S, R = 4 + 2 * ROWS, BW = TX + 2;
     const size_t lds = (size_t)R * RW * 48 + (size_t)2 * ROWS * 2 * BW * 4 + 16;
-    // per device: one process may own contexts on several GPUs (include/svgf.h: handle-based), and the opt-in to more
-    // than 64 KB of dynamic LDS is a per-device function attribute
-    static bool attr_done[64] = {};
+    static SvgfLaunchCache cache;
     int dev_id = 0;
-    (void)hipGetDevice(&dev_id);
-    if (dev_id < 0 || dev_id >= 64) dev_id = 0;
-    if (!attr_done[dev_id]) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_atrous_strip<LOG2S, TX, ROWS, HASVAR>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        attr_done[dev_id] = true;
-    }
+    if (hipError_t e = cache.init(reinterpret_cast<const void *>(&k_atrous_strip<LOG2S, TX, ROWS, HASVAR>), (int)lds, &dev_id); e != hipSuccess) return e;
+    const int n_cu = cache.n_cu[dev_id];
     StripGeom gm;
     gm.n_strips = (a.W + TX - 1) / TX;
     const int nb_max = (a.H + S - 1) / S;
     // Segment length: every (strip, phase, segment) is one workgroup, and LDS admits `bpc` workgroups per CU, so the
     // grid runs in ceil(blocks / (CUs * bpc)) rounds of equal-length workgroups.  Pick the segment length L that
     // minimises rounds * (L + fixed cost), the fixed cost being the 4 halo rows + the exposed prologue latency.
-    static int n_cu = 0;
-    if (!n_cu) {
-        int dev = 0;
-        (void)hipGetDevice(&dev);
-        if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) n_cu = 256;
-    }
     int bpc = (int)((160 * 1024) / lds);
     constexpr int kLoaderThreads = loader_threads(TX, ROWS);
     if (bpc > 2048 / (TX * ROWS + kLoaderThreads)) bpc = 2048 / (TX * ROWS + kLoaderThreads);

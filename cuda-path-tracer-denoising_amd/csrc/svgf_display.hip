@@ -8,6 +8,7 @@
 //                       mirrored in x (the renderer's rays run right-to-left), each channel is clamp(v,0,1) * 255.f
 //                       truncated to a byte, written as an 8-bit RGB PNG.  The reference encodes with stb_image_write;
 //                       this writer emits stored (uncompressed) deflate blocks — same pixels, larger file, no dependency.
+#include "svgf_kernels.h"
 #include "../../include/svgf.h"
 
 #include <hip/hip_runtime.h>
@@ -82,7 +83,8 @@ int svgf_display_pack(int device, void *pbo_rgba8_dev, const void *left_rgb_dev,
 {
     if (!pbo_rgba8_dev || !left_rgb_dev || !right_rgb_dev || width <= 0 || height <= 0) return SVGF_ERR_INVALID_ARG;
     if ((long long)width * height >= (1LL << 31) / 16) return SVGF_ERR_UNSUPPORTED;
-    if (hipSetDevice(device) != hipSuccess) return SVGF_ERR_NO_DEVICE;
+    SvgfDeviceGuard dev_guard(device);
+    if (!dev_guard.ok) return SVGF_ERR_NO_DEVICE;
     const int n = width * height;
     hipLaunchKernelGGL(k_display_pack, dim3((n + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream),
                        static_cast<uchar4 *>(pbo_rgba8_dev), static_cast<const float *>(left_rgb_dev),

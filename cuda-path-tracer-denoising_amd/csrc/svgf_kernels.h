@@ -12,6 +12,46 @@
 // frame, by the temporal (or prepare) kernel, which splits it into the NRM/POS/GID planes the a-trous levels read.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <mutex>
+
+// Per-device launch state of ONE kernel instantiation (a function-local static of its launcher).  The opt-in to more than
+// 64 KB of dynamic LDS is a per-device function attribute and the CU count a device property; the ABI allows one context
+// per GPU in one process, driven from several host threads, so both are set up once per device under std::call_once.
+struct SvgfLaunchCache {
+    std::once_flag once[64];
+    hipError_t err[64];
+    int n_cu[64];
+    // returns the current device's slot (0..63) through *dev; the attribute is only requested when lds_bytes > 0
+    hipError_t init(const void *kernel, int lds_bytes, int *dev)
+    {
+        int d = 0;
+        (void)hipGetDevice(&d);
+        if (d < 0 || d >= 64) d = 0;
+        std::call_once(once[d], [&]() {
+            err[d] = lds_bytes > 0 ? hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) : hipSuccess;
+            int n = 0;
+            if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, d) != hipSuccess || n <= 0) n = 256;
+            n_cu[d] = n;
+        });
+        *dev = d;
+        return err[d];
+    }
+};
+
+// Entry points switch to their context's device and put the caller's device back on return (a host that drives several
+// GPUs from one thread — torch, the renderer through denoise_compat — must not find its current device changed).
+struct SvgfDeviceGuard {
+    int prev;
+    bool ok;
+    explicit SvgfDeviceGuard(int device) : prev(-1), ok(false)
+    {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        ok = (prev == device) || hipSetDevice(device) == hipSuccess;
+    }
+    ~SvgfDeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+    SvgfDeviceGuard(const SvgfDeviceGuard &) = delete;
+    SvgfDeviceGuard &operator=(const SvgfDeviceGuard &) = delete;
+};
 
 struct AtrousArgs {
     const float4 *src;        // CV plane read (colour + variance snapshot)
@@ -41,17 +81,20 @@ struct TemporalArgs {
     int W, H;
     float color_alpha_min, moment_alpha_min;
     float reproj_sx, reproj_sy;   // SvgfParams::reproj_scale; 0 = reference mapping
+    const float *pos_prev;    // previous frame's positions (packed float3), read only when pos_tol > 0
+    float pos_tol;            // SvgfParams::reproj_position_tol; 0 = the reference's consistency test
 };
 
 hipError_t launch_temporal(const TemporalArgs &a, hipStream_t s, bool single_wave_blocks);
+// SvgfParams::spatial_variance_frames (f4): variance of short-history pixels from the 7x7 neighbourhood's moments
+hipError_t launch_spatial_variance(float4 *cv_acc, const float2 *mom_acc, const int *hlen_upd, const float *nrm, const int *gid,
+                                   int W, int H, int K, hipStream_t s);
 // non-temporal mode: variance = 10, colour = input, split G-buffer (reference EstimateVariance :320-329 + :370)
 hipError_t launch_prepare(const float *in_rgb, const float *gbuf, float4 *cv, float *nrm, int *gid, float *pos,
                           int W, int H, hipStream_t s);
 hipError_t launch_atrous_gather(const AtrousArgs &a, hipStream_t s);   // strict one-thread-per-pixel gather kernel
 hipError_t launch_atrous_strip(const AtrousArgs &a, hipStream_t s);    // LDS strip-marching kernel (fast path)
 bool       atrous_strip_supported(const AtrousArgs &a);
-hipError_t launch_atrous_share(const AtrousArgs &a, hipStream_t s);    // strip kernel with shared geometric weights (steps 2,4,8)
-bool       atrous_share_supported(const AtrousArgs &a);
 hipError_t launch_atrous_lane(const AtrousArgs &a, hipStream_t s);     // lane-marching kernel, symmetric terms shared by DPP (steps 2,4,8)
 bool       atrous_lane_supported(const AtrousArgs &a);
 hipError_t launch_atrous_lattice(const AtrousArgs &a, hipStream_t s);  // lattice sub-images in LDS (steps >= 64)

@@ -51,6 +51,15 @@ __device__ __forceinline__ int reproj_valid(const TemporalArgs &a, float qx, flo
     return q;
 }
 
+// SvgfParams::reproj_position_tol (f4 extension): the tap's previous-frame world position must lie within tol of the
+// current pixel's
+__device__ __forceinline__ int reproj_valid_pos(const TemporalArgs &a, int q, float px, float py, float pz)
+{
+    if (q < 0 || !(a.pos_tol > 0.0f)) return q;
+    const float *pp = a.pos_prev + 3 * (size_t)q;
+    return (dist3_strict(pp[0], pp[1], pp[2], px, py, pz) <= a.pos_tol) ? q : -1;
+}
+
 template <int BLOCK>
 __global__ __launch_bounds__(BLOCK) void k_temporal(TemporalArgs a)
 {
@@ -92,7 +101,7 @@ __global__ __launch_bounds__(BLOCK) void k_temporal(TemporalArgs a)
         int q4[4];
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            q4[k] = reproj_valid(a, fx + (float)(k & 1), fy + (float)(k >> 1), gid, nx, ny, nz);
+            q4[k] = reproj_valid_pos(a, reproj_valid(a, fx + (float)(k & 1), fy + (float)(k >> 1), gid, nx, ny, nz), px, py, pz);
             valid = valid && (q4[k] >= 0);
         }
 
@@ -119,7 +128,7 @@ __global__ __launch_bounds__(BLOCK) void k_temporal(TemporalArgs a)
                 for (int xx = -1; xx <= 1; xx++) {
                     // the four taps with xx, yy in {0, 1} are the bilinear taps tested above: same arguments, same answer
                     const int q = (xx >= 0 && yy >= 0) ? q4[xx + 2 * yy]
-                                                       : reproj_valid(a, fx + (float)xx, fy + (float)yy, gid, nx, ny, nz);
+                                                       : reproj_valid_pos(a, reproj_valid(a, fx + (float)xx, fy + (float)yy, gid, nx, ny, nz), px, py, pz);
                     if (q >= 0) {
                         const float4 ch = a.cv_hist[q];
                         const float2 mh = a.mom_hist[q];
@@ -160,6 +169,53 @@ hipError_t launch_temporal(const TemporalArgs &a, hipStream_t s, bool single_wav
     // one-wave workgroups can be placed in them, four-wave workgroups cannot.
     if (single_wave_blocks) hipLaunchKernelGGL(k_temporal<64>, dim3(div_up(n, 64)), dim3(64), 0, s, a);
     else hipLaunchKernelGGL(k_temporal<SVGF_BLOCK>, dim3(div_up(n, SVGF_BLOCK)), dim3(SVGF_BLOCK), 0, s, a);
+    return hipGetLastError();
+}
+
+// ----------------------------------------------------------------------------------------------------
+// SvgfParams::spatial_variance_frames (f4 extension; the reference's EstimateVariance is a stub, src/denoise.cu:320-329):
+// pixels whose updated history is shorter than K frames take their variance from the luminance moments of their 7x7
+// neighbourhood (taps with the same geomId and |n_q - n_p| <= 0.1, the reference's own consistency predicate; sums in
+// raster order), boosted by max(1, 4 / history length) (Schied et al. 2017, section 4.2).  Writes cv_acc.w only.
+// ----------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(SVGF_BLOCK) void k_spatial_variance(float4 *__restrict__ cv_acc, const float2 *__restrict__ mom_acc,
+                                                                const int *__restrict__ hlen_upd, const float *__restrict__ nrm,
+                                                                const int *__restrict__ gid, int W, int H, int K)
+{
+#pragma clang fp contract(off)
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * (SVGF_BLOCK / 64) + (threadIdx.x >> 6);
+    if (x >= W || y >= H) return;
+    const int p = x + y * W;
+    const int hl = hlen_upd[p];
+    if (hl >= K) return;
+    const int g0 = gid[p];
+    const float nx = nrm[3 * (size_t)p], ny = nrm[3 * (size_t)p + 1], nz = nrm[3 * (size_t)p + 2];
+    float s1 = 0.0f, s2 = 0.0f, cnt = 0.0f;
+    for (int yy = -3; yy <= 3; yy++)
+        for (int xx = -3; xx <= 3; xx++) {
+            const int qx = x + xx, qy = y + yy;
+            if (qx < 0 || qx >= W || qy < 0 || qy >= H) continue;
+            const int q = qx + qy * W;
+            if (q != p) {
+                if (gid[q] != g0) continue;
+                const float *n = nrm + 3 * (size_t)q;
+                if (!(dist3_strict(n[0], n[1], n[2], nx, ny, nz) <= 1e-1f)) continue;
+            }
+            const float2 m = mom_acc[q];
+            s1 += m.x; s2 += m.y; cnt += 1.0f;
+        }
+    const float m1 = s1 / cnt, m2 = s2 / cnt;
+    float v = m2 - m1 * m1;
+    v = v > 0.0f ? v : 0.0f;
+    const float boost = 4.0f / (float)(hl > 0 ? hl : 1);
+    cv_acc[p].w = v * (boost > 1.0f ? boost : 1.0f);
+}
+
+hipError_t launch_spatial_variance(float4 *cv_acc, const float2 *mom_acc, const int *hlen_upd, const float *nrm, const int *gid,
+                                   int W, int H, int K, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_spatial_variance, dim3((W + 63) / 64, (H + SVGF_BLOCK / 64 - 1) / (SVGF_BLOCK / 64)), dim3(SVGF_BLOCK), 0, s,
+                       cv_acc, mom_acc, hlen_upd, nrm, gid, W, H, K);
     return hipGetLastError();
 }
 

@@ -7,6 +7,7 @@
 // the text and builds the SvgfSceneGeom records; this kernel casts the primary rays against them and writes the
 // denoiser's inputs with the same shading / noise stub as svgf_synth.hip.  Oracle: scene.render_scene (numpy), mirrored
 // here operation for operation in fp32 with contraction off.
+#include "svgf_kernels.h"
 #include "../../include/svgf.h"
 
 #include <hip/hip_runtime.h>
@@ -156,7 +157,8 @@ extern "C" int svgf_scene_render(int device, void *out_rgb_dev, void *out_gbuffe
     if (!out_rgb_dev || !out_gbuffer_dev || !cam || !sp || !geoms || !light || width <= 0 || height <= 0) return SVGF_ERR_INVALID_ARG;
     if (n_geoms < 0 || n_geoms > SVGF_SCENE_MAX_GEOMS) return SVGF_ERR_INVALID_ARG;
     if ((long long)width * height >= (1LL << 31) / 16) return SVGF_ERR_UNSUPPORTED;
-    if (hipSetDevice(device) != hipSuccess) return SVGF_ERR_NO_DEVICE;
+    SvgfDeviceGuard dev_guard(device);
+    if (!dev_guard.ok) return SVGF_ERR_NO_DEVICE;
     hipStream_t s = static_cast<hipStream_t>(stream);
     SvgfSceneGeom *d_geoms = nullptr;
     const size_t bytes = sizeof(SvgfSceneGeom) * (size_t)(n_geoms > 0 ? n_geoms : 1);

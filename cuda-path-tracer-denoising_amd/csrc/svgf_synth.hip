@@ -7,9 +7,10 @@
 // scene SURVEY.md §8(d) prescribes (5 walls, 2 spheres, 1 box, Lambert shading, multiplicative noise, fireflies).
 // The scene and every arithmetic step are those of cuda-path-tracer-denoising_amd/synth.py (render_frame with
 // noise_model="hash"), operation for operation in fp32 with contraction off, so the two agree bit for bit
-// (tests/test_synth_device_gpu.py); the numpy version is the oracle of this row.
+// (tests/test_synth_producer.py); the numpy version is the oracle of this row.
 //
 // One thread per pixel, 64 B written per pixel (12 colour + 52 texel), no reads: HBM-write-bound.
+#include "svgf_kernels.h"
 #include "../../include/svgf.h"
 
 #include <hip/hip_runtime.h>
@@ -191,7 +192,8 @@ int svgf_synth_render(int device, void *out_rgb_dev, void *out_gbuffer_dev, int 
 {
     if (!out_rgb_dev || !out_gbuffer_dev || !cam || !sp || width <= 0 || height <= 0) return SVGF_ERR_INVALID_ARG;
     if ((long long)width * height >= (1LL << 31) / 16) return SVGF_ERR_UNSUPPORTED;
-    if (hipSetDevice(device) != hipSuccess) return SVGF_ERR_NO_DEVICE;
+    SvgfDeviceGuard dev_guard(device);
+    if (!dev_guard.ok) return SVGF_ERR_NO_DEVICE;
     SynthArgs a;
     for (int c = 0; c < 3; c++) { a.right[c] = cam->right[c]; a.up[c] = cam->up[c]; a.view[c] = cam->view[c]; a.o[c] = cam->position[c]; }
     a.plx = sp->pixel_length[0]; a.ply = sp->pixel_length[1];

@@ -10,8 +10,12 @@
  * globals + `scene->state.camera` at call time (src/main.h:39-69, src/denoise.cu:350-399).
  * Here the same information crosses the boundary explicitly: a context handle
  * (so one context per GPU can coexist), a camera block and a parameter block.
- * `include/denoise_compat.h` + `cuda-path-tracer-denoising_amd/csrc/denoise_compat.cpp`
- * rebuild the three legacy functions on top of these entry points.
+ * `cuda-path-tracer-denoising_amd/csrc/denoise_compat.cpp` rebuilds the three legacy functions (declared by the
+ * renderer's own denoise.h) on top of these entry points; INTEGRATION.md shows the binding.
+ *
+ * Every entry point switches to its context's device and restores the caller's current device before it returns.
+ * Contexts are independent: one per GPU (or several per GPU) may be driven from different host threads; one context
+ * must not be used from two threads at once.
  *
  * Plain C: pointers and sizes only, no C++/torch types.  All image pointers are
  * DEVICE pointers unless the function name ends in `_host`.
@@ -28,7 +32,7 @@ extern "C" {
 #endif
 
 #define SVGF_VERSION_MAJOR 0
-#define SVGF_VERSION_MINOR 2
+#define SVGF_VERSION_MINOR 3
 
 /* ---- error codes (every entry point returns one of these; the library never exits) ---- */
 #define SVGF_OK                 0
@@ -77,9 +81,10 @@ typedef struct SvgfParams {
     /* --- extensions; 0 == reference behaviour --- */
     int   kernel_variant;     /* 0 auto (lane-marching kernel for steps 2-8, LDS strip kernel for steps 16-32, lattice
                                  sub-image kernel for steps >= 64, gather where none applies), 1 strict gather kernel,
-                                 2 LDS strip kernel for every step 2-32 (error if a step is unsupported), 3 experimental:
-                                 two-pass shared-weight kernel for steps 2-8 (correct, slower), 4 lane-marching kernel for
-                                 steps 2-8 + strip + lattice (what auto selects) */
+                                 2 LDS strip kernel for every step 2-32 (error if a step is unsupported, raised before
+                                 anything is enqueued), 3 retired (was an experimental shared-weight kernel, now under
+                                 tools/experiments/; SVGF_ERR_INVALID_ARG), 4 lane-marching kernel for steps 2-8 + strip +
+                                 lattice whatever the image width */
     int   inputs_ready;       /* 1: in_rgb/gbuffer are complete when svgf_denoise is CALLED (no producer still pending on
                                  `stream`).  Lets the temporal pass of this frame run on an internal stream concurrently
                                  with the previous frame's trailing a-trous levels.  0: everything is ordered on `stream`. */
@@ -92,6 +97,18 @@ typedef struct SvgfParams {
     int   paper_steps;        /* "next" row f4: 1 = a-trous level k (1-based) uses dilation 2^(k-1) = 1, 2, 4, ... as in the
                                  SVGF paper; 0 = the reference's 2^k = 2, 4, 8, ... (its level counter starts at 1,
                                  src/denoise.cu:98,386).  Appended in ABI 0.2 (sizeof(SvgfParams) 68 -> 72). */
+    float reproj_position_tol;/* "next" row f4, the consistency test the reference's README (:39) names but isReprjValid
+                                 (src/denoise.cu:172-182) does not have: if > 0, a history tap is also rejected when the world
+                                 position stored for it in the previous frame lies further than this from the current
+                                 pixel's position (Schied et al. 2017 test depth; world position is what the G-buffer of this
+                                 renderer carries).  0 = the reference's test (bounds, geomId, normal).  ABI 0.3. */
+    int   spatial_variance_frames; /* "next" row f4, the spatial variance estimate the reference leaves as a TODO
+                                 (src/denoise.cu:326, EstimateVariance is a constant): if K > 0, a pixel whose updated history
+                                 is shorter than K frames takes its variance from the luminance moments of its 7x7
+                                 neighbourhood instead of from its own (Schied et al. 2017, section 4.2): taps that pass the
+                                 reference's own consistency predicate (same geomId, |n_q - n_p| <= 0.1) count with weight 1,
+                                 variance = max(0, mean(m2) - mean(m1)^2) * max(1, 4 / history length).  0 = reference
+                                 (temporal variance, 100 without history).  ABI 0.3 (sizeof(SvgfParams) 72 -> 80). */
 } SvgfParams;
 
 #define SVGF_MAX_LEVELS 10
@@ -191,7 +208,9 @@ int svgf_synth_render(int device, void *out_rgb_dev, void *out_gbuffer_dev, int 
  * The reference's scenes are transformed unit cubes / spheres (src/scene.cpp:47-117, src/intersections.h:50,104; meshes
  * belong to the out-of-scope path tracer).  The host side (scene.py: the MATERIAL / OBJECT / CAMERA text format) builds
  * these records; svgf_scene_render casts the primary rays against them and writes colour + G-buffer like
- * svgf_synth_render does for its built-in scene.  geomId = index into `geoms`.  `geoms` and `light` are host memory. */
+ * svgf_synth_render does for its built-in scene.  geomId = index into `geoms`.  `geoms` and `light` are host memory;
+ * `geoms` is uploaded with an asynchronous copy on `stream` and must stay valid and unchanged until the stream has
+ * consumed it (synchronise the stream before freeing or rewriting it). */
 #define SVGF_SCENE_MAX_GEOMS 64
 typedef struct SvgfSceneGeom {
     int   type;              /* 0 cube [-0.5,0.5]^3, 1 sphere r = 0.5 (object space) */

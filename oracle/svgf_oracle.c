@@ -189,6 +189,11 @@ void svgf_oracle_atrous(const float *colorin, float *colorout, const float *vari
 
 /* isReprjValid (:172-182) for integer current pixel p and a float previous coordinate (qx,qy) that is
  * integral-valued when finite. Returns the previous pixel index or -1. */
+/* pos_tol: SvgfParams::reproj_position_tol (extension; 0 = the reference's test) */
+static float g_pos_tol = 0.0f;
+#ifdef _OPENMP
+#pragma omp threadprivate(g_pos_tol)
+#endif
 static int reproj_valid(int W, int H, int p, float qx, float qy,
                         const SvgfGBufferTexel *cur, const SvgfGBufferTexel *prev)
 {
@@ -197,14 +202,16 @@ static int reproj_valid(int W, int H, int p, float qx, float qy,
     int q = (int)(qx + qy * (float)W);
     if (prev[q].geomId == -1 || prev[q].geomId != cur[p].geomId) return -1;
     if (dist3(prev[q].normal, cur[p].normal) > 1e-1f) return -1;
+    if (g_pos_tol > 0.0f && !(dist3(prev[q].position, cur[p].position) <= g_pos_tol)) return -1;
     return q;
 }
 
 static void backproject_pixel(int x, int y, float *variance_out, const int *hl, int *hl_upd,
                               const float *mom_hist, const float *col_hist, float *mom_acc, float *col_acc,
                               const float *cur_col, const SvgfGBufferTexel *cur_g, const SvgfGBufferTexel *prev_g,
-                              const float *M, int W, int H, float ca_min, float ma_min, float rsx, float rsy)
+                              const float *M, int W, int H, float ca_min, float ma_min, float rsx, float rsy, float pos_tol)
 {
+    g_pos_tol = pos_tol;
     const int p = x + y * W;
     const int N = hl[p];                                   /* at the CURRENT pixel (:194) */
     const float *s = &cur_col[3 * p];
@@ -300,7 +307,7 @@ void svgf_oracle_backproject_ex(float *variance_out, const int *history_length, 
                                 const float *current_color, const SvgfGBufferTexel *current_gbuffer,
                                 const SvgfGBufferTexel *prev_gbuffer, const float prev_viewmat[16],
                                 int W, int H, float color_alpha_min, float moment_alpha_min, int nthreads,
-                                float reproj_sx, float reproj_sy)
+                                float reproj_sx, float reproj_sy, float pos_tol)
 {
     (void)nthreads;
 #ifdef _OPENMP
@@ -310,7 +317,44 @@ void svgf_oracle_backproject_ex(float *variance_out, const int *history_length, 
         for (int x = 0; x < W; x++)
             backproject_pixel(x, y, variance_out, history_length, history_length_update, moment_history,
                               color_history, moment_acc, color_acc, current_color, current_gbuffer,
-                              prev_gbuffer, prev_viewmat, W, H, color_alpha_min, moment_alpha_min, reproj_sx, reproj_sy);
+                              prev_gbuffer, prev_viewmat, W, H, color_alpha_min, moment_alpha_min, reproj_sx, reproj_sy, pos_tol);
+}
+
+/* SvgfParams::spatial_variance_frames (extension; the reference's EstimateVariance is a TODO stub,
+ * src/denoise.cu:320-329).  Pixels whose updated history is shorter than K frames: variance from the luminance moments of
+ * the 7x7 neighbourhood, taps accepted by the reference's own consistency predicate (geomId, normal distance <= 0.1;
+ * src/denoise.cu:176-180), centre always; sums in raster order in fp32; boosted by max(1, 4 / history length)
+ * (Schied et al. 2017, section 4.2). */
+void svgf_oracle_spatial_variance(float *variance, const float *moment_acc, const int *history_length_update,
+                                  const SvgfGBufferTexel *g, int W, int H, int K, int nthreads)
+{
+    (void)nthreads;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 4) num_threads(nthreads > 0 ? nthreads : 1)
+#endif
+    for (int y = 0; y < H; y++)
+        for (int x = 0; x < W; x++) {
+            const int p = x + y * W;
+            const int hl = history_length_update[p];
+            if (hl >= K) continue;
+            float s1 = 0.0f, s2 = 0.0f, cnt = 0.0f;
+            for (int yy = -3; yy <= 3; yy++)
+                for (int xx = -3; xx <= 3; xx++) {
+                    const int qx = x + xx, qy = y + yy;
+                    if (qx < 0 || qx >= W || qy < 0 || qy >= H) continue;
+                    const int q = qx + qy * W;
+                    if (q != p) {
+                        if (g[q].geomId != g[p].geomId) continue;
+                        if (!(dist3(g[q].normal, g[p].normal) <= 1e-1f)) continue;
+                    }
+                    s1 += moment_acc[2 * q]; s2 += moment_acc[2 * q + 1]; cnt += 1.0f;
+                }
+            const float m1 = s1 / cnt, m2 = s2 / cnt;
+            float v = m2 - m1 * m1;
+            v = v > 0.0f ? v : 0.0f;
+            const float boost = 4.0f / (float)(hl > 0 ? hl : 1);
+            variance[p] = v * (boost > 1.0f ? boost : 1.0f);
+        }
 }
 
 void svgf_oracle_backproject(float *variance_out, const int *history_length, int *history_length_update,
@@ -322,7 +366,7 @@ void svgf_oracle_backproject(float *variance_out, const int *history_length, int
 {   /* the reference's BackProjection */
     svgf_oracle_backproject_ex(variance_out, history_length, history_length_update, moment_history, color_history,
                                moment_acc, color_acc, current_color, current_gbuffer, prev_gbuffer, prev_viewmat, W, H,
-                               color_alpha_min, moment_alpha_min, nthreads, 0.0f, 0.0f);
+                               color_alpha_min, moment_alpha_min, nthreads, 0.0f, 0.0f, 0.0f);
 }
 
 /* ------------------------------------------------------------------------------------------------ */
@@ -460,7 +504,10 @@ int svgf_oracle_denoise(oracle_ctx *c, float *out, const float *in, const SvgfGB
         svgf_oracle_backproject_ex(c->variance, c->history_length, c->history_length_update, c->moment_history,
                                 c->color_history, c->moment_acc, c->color_acc, in, g, c->gbuffer_prev,
                                 c->view_prev, W, H, p->color_alpha, p->moment_alpha, c->nthreads,
-                                p->reproj_scale[0], p->reproj_scale[1]);
+                                p->reproj_scale[0], p->reproj_scale[1], p->reproj_position_tol);
+        if (p->spatial_variance_frames > 0)
+            svgf_oracle_spatial_variance(c->variance, c->moment_acc, c->history_length_update, g, W, H,
+                                         p->spatial_variance_frames, c->nthreads);
         memcpy(c->color_history, c->color_acc, n * 3 * sizeof(float));
     } else {
         for (size_t k = 0; k < n; k++) c->variance[k] = 10.0f;

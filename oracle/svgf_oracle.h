@@ -53,14 +53,18 @@ void svgf_oracle_backproject(float *variance_out, const int *history_length, int
                              const float *current_color, const SvgfGBufferTexel *current_gbuffer,
                              const SvgfGBufferTexel *prev_gbuffer, const float prev_viewmat[16],
                              int W, int H, float color_alpha_min, float moment_alpha_min, int nthreads);
-/* the same with SvgfParams::reproj_scale (extension); (0, 0) == svgf_oracle_backproject */
+/* the same with SvgfParams::reproj_scale and ::reproj_position_tol (extensions); (0, 0, 0) ==
+ * svgf_oracle_backproject */
 void svgf_oracle_backproject_ex(float *variance_out, const int *history_length, int *history_length_update,
                              const float *moment_history, const float *color_history,
                              float *moment_acc, float *color_acc,
                              const float *current_color, const SvgfGBufferTexel *current_gbuffer,
                              const SvgfGBufferTexel *prev_gbuffer, const float prev_viewmat[16],
                              int W, int H, float color_alpha_min, float moment_alpha_min, int nthreads,
-                                float reproj_sx, float reproj_sy);
+                                float reproj_sx, float reproj_sy, float pos_tol);
+/* SvgfParams::spatial_variance_frames (extension, f4): 7x7 spatial variance estimate for histories shorter than K */
+void svgf_oracle_spatial_variance(float *variance, const float *moment_acc, const int *history_length_update,
+                                  const SvgfGBufferTexel *g, int W, int H, int K, int nthreads);
 
 /* GetViewMatrix, src/denoise.cu:342-347: inverse of the column-major matrix [right|up|view|position]. */
 void svgf_oracle_view_matrix(const SvgfCamera *cam, float out_colmajor[16]);

@@ -30,7 +30,7 @@ def test_struct_layouts_match_reference(pkg):
     assert dt.itemsize == 52
     assert [dt.fields[k][1] for k in ("normal", "position", "albedo", "ialbedo", "geomId")] == [0, 12, 24, 36, 48]
     assert ctypes.sizeof(pkg.SvgfCamera) == 48
-    assert ctypes.sizeof(pkg.SvgfParams) == 18 * 4
+    assert ctypes.sizeof(pkg.SvgfParams) == 20 * 4
 
 
 def test_params_default_matches_reference_ui_defaults(pkg):
@@ -40,7 +40,7 @@ def test_params_default_matches_reference_ui_defaults(pkg):
     q = pkg.reference_defaults()        # reference src/main.cpp:49-62
     for name, _ in pkg.SvgfParams._fields_[:15]:
         assert getattr(p, name) == pytest.approx(getattr(q, name)), name
-    assert lib.svgf_version() == (0 << 16) | 2
+    assert lib.svgf_version() == (0 << 16) | 3
 
 
 def test_error_paths_without_gpu(pkg):

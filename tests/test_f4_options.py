@@ -1,0 +1,124 @@
+"""SURVEY.md §8(f) row f4, remaining items: the position test in the reprojection (SvgfParams::reproj_position_tol) and
+the spatial variance estimate for short histories (SvgfParams::spatial_variance_frames).
+
+Neither exists in the reference: README.md:39 names a position test that isReprjValid (src/denoise.cu:172-182) does not
+perform, and EstimateVariance (src/denoise.cu:320-329) is a constant with a TODO.  Both are defined here from Schied et
+al. 2017 (sections 4.1, 4.2) and carried by the CPU oracle as well, so the parity bar is the hot path's: integer state
+bit-exact, fp32 temporal state bit-exact, <= 1e-4 relative after the a-trous levels.  0 / 0 must be the reference path.
+"""
+import numpy as np
+import pytest
+
+from conftest import relerr
+
+
+def _scales(pkg, W, H):
+    plx, ply = pkg.synth._pixel_length(W, H, 45.0)
+    return float(plx) * W / 2.0, float(ply) * H / 2.0
+
+
+def _params(pkg, W, H, tol=0.0, K=0, nlevel=5):
+    p = pkg.reference_defaults().set(temporal_enable=1, spatial_enable=1, atrous_nlevel=nlevel, history_level=1,
+                                     reproj_position_tol=tol, spatial_variance_frames=K)
+    p.reproj_scale[0], p.reproj_scale[1] = _scales(pkg, W, H)       # exact reprojection, so that histories survive at 16:9
+    return p
+
+
+def test_zero_is_the_reference_path(pkg, orc):
+    W, H = 96, 64
+    frames = [pkg.synth.render_frame(W, H, f, seed=2, moving=True, noise_model="hash") for f in range(3)]
+    outs = []
+    for pr in (pkg.reference_defaults().set(temporal_enable=1, spatial_enable=1),
+               pkg.reference_defaults().set(temporal_enable=1, spatial_enable=1, reproj_position_tol=0.0, spatial_variance_frames=0)):
+        o = orc.Oracle(pkg, W, H)
+        outs.append([o.denoise(c, g, cam, pr) for c, g, cam in frames])
+        o.free()
+    for a, b in zip(*outs):
+        assert np.array_equal(a, b)
+
+
+def test_position_test_rejects_what_moved(pkg, orc):
+    """Moving camera: surfaces slide under the pixels, so a world-position tolerance below the per-frame motion rejects
+    taps the geomId + normal test accepts (large flat walls: same id, same normal, different point).  History lengths
+    with the test are never longer than without, and shorter on a visible share of the pixels."""
+    W, H, nf = 320, 180, 5
+    frames = [pkg.synth.render_frame(W, H, f, seed=4, moving=True, noise_model="hash") for f in range(nf)]
+    hl = {}
+    for tol in (0.0, 1e-4, 10.0):
+        o = orc.Oracle(pkg, W, H, threads=4)
+        for c, g, cam in frames:
+            o.denoise(c, g, cam, _params(pkg, W, H, tol=tol, nlevel=1))
+        hl[tol] = o.read_state(0)
+        o.free()
+    assert np.array_equal(hl[10.0], hl[0.0])                  # a tolerance larger than the scene changes nothing
+    assert np.all(hl[1e-4] <= hl[0.0])
+    assert (hl[1e-4] < hl[0.0]).mean() > 0.2, float((hl[1e-4] < hl[0.0]).mean())
+
+
+def test_spatial_variance_replaces_the_constant(pkg, orc):
+    """Frame 0 has no history anywhere: the reference writes variance = 100 (src/denoise.cu:315); with K = 4 every pixel
+    gets the 7x7 estimate instead: zero where the neighbourhood is one flat colour, positive on noisy surfaces, x4 boost."""
+    W, H = 128, 72
+    c, g, cam = pkg.synth.render_frame(W, H, 0, seed=6, noise_model="hash")
+    res = {}
+    for K in (0, 4):
+        o = orc.Oracle(pkg, W, H, threads=4)
+        o.denoise(c, g, cam, _params(pkg, W, H, K=K, nlevel=0))
+        res[K] = o.read_state(3)
+        o.free()
+    assert np.all(res[0] == 100.0)
+    assert np.all(res[4] >= 0.0) and np.isfinite(res[4]).all() and (res[4] != 100.0).mean() > 0.99
+    lum = (0.2126 * c[..., 0].astype(np.float64) + 0.7152 * c[..., 1] + 0.0722 * c[..., 2])
+    y, x = 30, 40                                              # an interior pixel: brute-force restatement
+    s1 = s2 = n = 0.0
+    for yy in range(-3, 4):
+        for xx in range(-3, 4):
+            q = (y + yy, x + xx)
+            if (yy, xx) != (0, 0):
+                if g["geomId"][q] != g["geomId"][y, x] or np.linalg.norm(g["normal"][q] - g["normal"][y, x]) > 0.1:
+                    continue
+            s1 += lum[q]; s2 += lum[q] ** 2; n += 1
+    want = max(0.0, s2 / n - (s1 / n) ** 2) * 4.0
+    assert res[4][y, x] == pytest.approx(want, rel=2e-4, abs=1e-7)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("W,H,moving,tol,K", [(320, 180, True, 0.05, 0), (320, 180, True, 0.0, 4), (200, 200, True, 0.02, 4),
+                                               (257, 131, False, 0.05, 6), (64, 48, True, 1e-4, 3)])
+def test_hip_matches_oracle_with_f4_options(pkg, orc, W, H, moving, tol, K):
+    nf = 5
+    params = _params(pkg, W, H, tol=tol, K=K)
+    d = pkg.Denoiser(W, H, 0)
+    d.set_capture(True)
+    o = orc.Oracle(pkg, W, H, threads=8)
+    for f in range(nf):
+        c, g, cam = pkg.synth.render_frame(W, H, f, seed=9, moving=moving, noise_model="hash")
+        got = d.denoise_host(c, g, cam, params)
+        ref = o.denoise(c, g, cam, params)
+        assert np.array_equal(d.read_state(0), o.read_state(0)), f"history length, frame {f}"
+        assert relerr(d.read_state(1), o.read_state(1)).max() <= 1e-5, f"moments, frame {f}"
+        assert relerr(d.read_state(3), o.read_state(3)).max() <= 2e-4 * (f + 1), f"variance after the temporal pass, frame {f}"
+        assert relerr(got, ref).max() <= 1e-4, f"frame {f}: {relerr(got, ref).max():.3e}"
+    d.free(); o.free()
+
+
+@pytest.mark.gpu
+def test_f4_options_with_overlap_are_bit_identical(pkg):
+    import torch
+    W, H, N = 640, 360, 6
+    frames = [pkg.synth.render_frame(W, H, f, seed=37, moving=True) for f in range(3)]
+    tin = [torch.from_numpy(f[0]).cuda() for f in frames]
+    tg = [torch.from_numpy(f[1].view(np.uint8).reshape(-1)).cuda() for f in frames]
+    res = {}
+    for ready in (0, 1):
+        p = _params(pkg, W, H, tol=0.05, K=4).set(inputs_ready=ready)
+        d = pkg.Denoiser(W, H, 0)
+        outs = [torch.empty((H, W, 3), dtype=torch.float32, device="cuda") for _ in range(N)]
+        torch.cuda.synchronize()
+        for k in range(N):
+            d.denoise(outs[k], tin[k % 3], tg[k % 3], frames[k % 3][2], p, stream=torch.cuda.current_stream())
+        d.sync()
+        res[ready] = [o.cpu().numpy() for o in outs]
+        d.free()
+    for k in range(N):
+        assert np.array_equal(res[0][k], res[1][k]), f"frame {k}"

@@ -1,20 +1,34 @@
-# round-end evidence run: tests, smoke, bench (3 configs), rocprofv3 kernel stats, PMC (SQ + HBM traffic), per-kernel probe
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/final; mkdir -p $O
+#!/bin/bash
+# Evidence run for profiles/ (round 2): tests, bench lines (same command the driver uses + the long run), rocprofv3 kernel
+# stats of the bench command, PMC passes (SQ + HBM traffic, FETCH and WRITE in separate passes as MI355X_MICROARCH.md
+# prescribes).  Run on the GPU box:  bash tools/final_run.sh   -> everything lands under gpurun_out/final/
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+O=$R/gpurun_out/final
+mkdir -p $O
 cd $R
-timeout 900 python -m pytest tests -x -q -m gpu 2>&1 | tail -2 > $O/pytest_gpu.txt; cat $O/pytest_gpu.txt
-python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1 | tee $O/smoke.txt
-python bench.py 2>/dev/null | tail -1 > $O/bench_1080p_static.json
-python bench.py --no-cpu-baseline --config 1080p-moving 2>/dev/null | tail -1 > $O/bench_1080p_moving.json
-python bench.py --no-cpu-baseline --config 4k-static 2>/dev/null | tail -1 > $O/bench_4k_static.json
-cut -c1-200 $O/bench_*.json
-python tools/probe.py --variants 1,0 --check --frames 6 2>&1 | grep -v amdgpu.ids > $O/probe_1080p.log
-python tools/probe.py --size 3840x2160 --variants 0 --frames 6 2>&1 | grep -v amdgpu.ids > $O/probe_4k.log
+python -m pytest tests -m gpu -q 2>&1 | tail -3 > $O/gpu_tests.txt
+python bench.py --steps 20 --warmup 5 > $O/bench_line_driver_cmd.json 2> $O/bench_driver_cmd.err
+python bench.py --no-cpu-baseline > $O/bench_line.json 2>/dev/null
+python bench.py --no-cpu-baseline --overlap > $O/bench_line_overlap.json 2>/dev/null
+python bench.py --no-cpu-baseline --config 1080p-moving > $O/bench_line_1080p_moving.json 2>/dev/null
+python bench.py --no-cpu-baseline --config 4k-static > $O/bench_line_4k_static.json 2>/dev/null
+python bench.py --config config1 > $O/bench_line_config1.json 2>/dev/null
+python tools/probe.py --variants 0 > $O/probe_1080p.log 2>&1
+python tools/probe.py --variants 0 --size 3840x2160 --frames 8 > $O/probe_4k.log 2>&1
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o r01 -- python $R/bench.py --steps 100 --warmup 10 --no-cpu-baseline > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats -d $O/prof -o p --output-format csv -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline > /dev/null 2>&1
+cp $(find $O/prof -name "*kernel_stats.csv" | head -1) $O/rocprofv3_kernel_stats_bench.csv 2>/dev/null
+rm -rf $O/prof
 rocprofv3 -i $R/tools/pmc2.txt -d $O/pmc_sq -o p --output-format csv -- python $R/tools/probe.py --variants 0 --frames 6 > /dev/null 2>&1
+python $R/tools/pmc_summary.py $O/pmc_sq "atrous" > $O/pmc_sq.txt
+python $R/tools/pmc_summary.py $O/pmc_sq "k_temporal" >> $O/pmc_sq.txt
+rm -rf $O/pmc_sq
 rocprofv3 -i $R/tools/pmc_traffic.txt -d $O/pmc_hbm -o p --output-format csv -- python $R/tools/probe.py --variants 0 --frames 6 > /dev/null 2>&1
-python $R/tools/pmc_summary.py $O/pmc_sq "k_" > $O/pmc_sq_summary.txt
-python $R/tools/pmc_summary.py $O/pmc_hbm "k_" > $O/pmc_hbm_summary.txt
-cp $O/stats/r01_kernel_stats.csv $O/kernel_stats_bench.csv
-rm -rf $O/stats $O/pmc_sq $O/pmc_hbm
-head -8 $O/kernel_stats_bench.csv | cut -c1-140; grep -E "FETCH|WRITE" $O/pmc_hbm_summary.txt | cut -c1-140
+python $R/tools/pmc_summary.py $O/pmc_hbm "atrous" > $O/pmc_hbm.txt
+python $R/tools/pmc_summary.py $O/pmc_hbm "k_temporal" >> $O/pmc_hbm.txt
+rm -rf $O/pmc_hbm
+SVGF_NO_VARIANCE_PLANE=1 rocprofv3 -i $R/tools/pmc_traffic.txt -d $O/pmc_hbm2 -o p --output-format csv -- python $R/tools/probe.py --variants 0 --frames 6 > /dev/null 2>&1
+python $R/tools/pmc_summary.py $O/pmc_hbm2 "atrous" > $O/pmc_hbm_no_variance_plane.txt
+rm -rf $O/pmc_hbm2
+rocminfo | grep -E "Marketing Name|Compute Unit|Max Clock" | head -12 > $O/gpu_box.txt; nproc >> $O/gpu_box.txt; grep -m1 "model name" /proc/cpuinfo >> $O/gpu_box.txt
+ls -la $O
