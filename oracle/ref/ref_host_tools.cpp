@@ -4,6 +4,9 @@
 // not reference code: it calls class Scene (src/scene.h:16-56) and class image (src/image.h:7-19) and prints / saves
 // what they produce.
 //   ref_host_tools scene <scene.txt>          -> JSON on stdout: camera, materials, geoms exactly as Scene parsed them
+//   ref_host_tools mesh <scene.txt> <out.bin> -> what Scene::loadMesh / Texture::Load produced (src/scene.cpp:234-330): int32 ntri, ngeoms,
+//                                                ntex; ngeoms x int32 {type, T_startidx, T_endidx}; ntri x 3 vertices x float {pos3, normal3,
+//                                                uv2} (world space); ntex x {int32 w, h, components; bytes}
 //   ref_host_tools png <out base name>        -> <base>.png written by image::savePNG (src/image.cpp:22-39) for a fixed
 //                                                37x5 pattern (in-range, byte boundaries, < 0, > 1, NaN, +-inf), after
 //                                                the x-mirror of saveImage() (src/main.cpp:131-152); <base>.f32 = pattern
@@ -49,6 +52,30 @@ int main(int argc, char **argv)
             printf("\"T_startidx\": %d, \"T_endidx\": %d}", g.type == MESH ? g.T_startidx : -1, g.type == MESH ? g.T_endidx : -1);
         }
         printf("],\n \"n_triangles\": %zu, \"n_textures\": %zu, \"n_lights\": %zu}\n", s->triangles.size(), s->textures.size(), s->lights.size());
+        return 0;
+    }
+    if (argc >= 4 && !strcmp(argv[1], "mesh")) {
+        Scene *s = new Scene(argv[2]);
+        FILE *o = fopen(argv[3], "wb");
+        if (!o) return 2;
+        const int32_t hdr[3] = { (int32_t)s->triangles.size(), (int32_t)s->geoms.size(), (int32_t)s->textures.size() };
+        fwrite(hdr, 4, 3, o);
+        for (const Geom &g : s->geoms) {
+            const int32_t r[3] = { g.type == SPHERE ? 1 : g.type == CUBE ? 0 : 2, g.type == MESH ? g.T_startidx : -1, g.type == MESH ? g.T_endidx : -1 };
+            fwrite(r, 4, 3, o);
+        }
+        for (const Triangle &t : s->triangles)
+            for (int k = 0; k < 3; k++) {
+                const float v[8] = { t.verts[k].pos.x, t.verts[k].pos.y, t.verts[k].pos.z, t.verts[k].normal.x, t.verts[k].normal.y, t.verts[k].normal.z,
+                                     t.verts[k].uv.x, t.verts[k].uv.y };
+                fwrite(v, 4, 8, o);
+            }
+        for (const Texture &t : s->textures) {
+            const int32_t d[3] = { t.width, t.height, t.components };
+            fwrite(d, 4, 3, o);
+            fwrite(t.image, 1, (size_t)t.width * t.height * t.components, o);
+        }
+        fclose(o);
         return 0;
     }
     if (argc >= 3 && !strcmp(argv[1], "png")) {
