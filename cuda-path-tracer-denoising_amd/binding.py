@@ -28,7 +28,7 @@ MAX_LEVELS = 10
 EXPORTS = ["svgf_version", "svgf_params_default", "svgf_create", "svgf_destroy", "svgf_reset", "svgf_denoise",
            "svgf_denoise_host", "svgf_sync", "svgf_last_error", "svgf_width", "svgf_height", "svgf_read_state",
            "svgf_set_capture", "svgf_profile_enable", "svgf_profile_stride", "svgf_profile_frames", "svgf_profile_read",
-           "svgf_synth_camera", "svgf_synth_render", "svgf_scene_render", "svgf_display_pack", "svgf_save_png"]
+           "svgf_synth_camera", "svgf_synth_render", "svgf_scene_render", "svgf_scene_render_mesh", "svgf_display_pack", "svgf_save_png"]
 
 
 class SvgfCamera(C.Structure):
@@ -123,6 +123,8 @@ def load_library(path: str | None = None):
     lib.svgf_synth_render.argtypes = [ip, vp, vp, ip, ip, C.POINTER(SvgfCamera), C.POINTER(SvgfSynthParams), vp]
     lib.svgf_scene_render.argtypes = [ip, vp, vp, ip, ip, C.POINTER(SvgfCamera), C.POINTER(SvgfSynthParams), vp, ip,
                                       C.POINTER(C.c_float), vp]
+    lib.svgf_scene_render_mesh.argtypes = [ip, vp, vp, ip, ip, C.POINTER(SvgfCamera), C.POINTER(SvgfSynthParams), vp, ip,
+                                           vp, vp, vp, vp, ip, C.POINTER(C.c_float), vp]
     lib.svgf_display_pack.argtypes = [ip, vp, vp, vp, ip, ip, vp]
     lib.svgf_save_png.argtypes = [C.c_char_p, vp, ip, ip, ip]
     if path == LIB_PATH:
@@ -308,3 +310,38 @@ def scene_render(out_rgb, out_gbuffer, width: int, height: int, camera, geoms: n
                                geoms.ctypes.data, int(len(geoms)), larr, s)
     if rc != SVGF_OK:
         raise SvgfError(f"svgf_scene_render failed ({rc})")
+
+
+def scene_render_mesh(out_rgb, out_gbuffer, width: int, height: int, camera, geoms: np.ndarray, geom_ids, tris, tri_ids, tri_albedo,
+                      frame: int, seed: int = 1, noise: float = 0.6, fireflies: float = 0.02, pixel_length=None, light=None,
+                      device: int = 0, stream=None):
+    """svgf_scene_render_mesh: primitives (`geoms`, geomId = geom_ids[k]) + world-space triangles (`tris` float32[n,3,8] =
+    pos, normal, uv per corner; geomId = tri_ids[i]; albedo = tri_albedo[i]).  The caller must keep the arrays alive until
+    the stream has run the kernel (the function synchronises when no stream is given)."""
+    from . import scene as _scene
+    from . import synth as _synth
+    lib = load_library()
+    cam = camera if isinstance(camera, SvgfCamera) else SvgfCamera.from_dict(camera)
+    if pixel_length is None:
+        fovy = camera.get("fovy_deg", 45.0) if isinstance(camera, dict) else 45.0
+        pixel_length = _synth._pixel_length(width, height, fovy)
+    sp = SvgfSynthParams(int(frame), int(seed), float(noise), float(fireflies))
+    sp.pixel_length[0] = float(pixel_length[0])
+    sp.pixel_length[1] = float(pixel_length[1])
+    geoms = np.ascontiguousarray(geoms, dtype=_scene.SCENE_GEOM_DTYPE)
+    gi = np.ascontiguousarray(geom_ids, dtype=np.int32)
+    tr = np.ascontiguousarray(tris, dtype=np.float32).reshape(-1, 24)
+    ti = np.ascontiguousarray(tri_ids, dtype=np.int32)
+    ta = np.ascontiguousarray(tri_albedo, dtype=np.float32).reshape(-1, 3)
+    lp = _scene.light_position(geoms) if light is None else np.asarray(light, dtype=np.float32)
+    larr = (C.c_float * 3)(float(lp[0]), float(lp[1]), float(lp[2]))
+    s = None if stream is None else (stream if isinstance(stream, int) else stream.cuda_stream)
+    rc = lib.svgf_scene_render_mesh(int(device), _ptr(out_rgb), _ptr(out_gbuffer), int(width), int(height), C.byref(cam), C.byref(sp),
+                                    geoms.ctypes.data if len(geoms) else None, int(len(geoms)), gi.ctypes.data if len(gi) else None,
+                                    tr.ctypes.data if len(tr) else None, ti.ctypes.data if len(ti) else None,
+                                    ta.ctypes.data if len(ta) else None, int(len(tr)), larr, s)
+    if rc != SVGF_OK:
+        raise SvgfError(f"svgf_scene_render_mesh failed ({rc})")
+    if stream is None:
+        import torch
+        torch.cuda.synchronize()

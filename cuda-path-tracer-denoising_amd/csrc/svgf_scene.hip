@@ -23,6 +23,11 @@ struct SceneArgs {
     float noise, fireflies, chroma_amp;
     int W, H, frame, seed, n_geoms;
     const SvgfSceneGeom *geoms;
+    const int *geom_ids;       // object index written as geomId for primitive k (null: k itself)
+    int n_tris;                // world-space triangles of the scene's meshes (Scene::loadMesh, src/scene.cpp:234-311)
+    const float *tris;         // n_tris x 3 vertices x {pos3, normal3, uv2}
+    const int *tri_ids;        // object index of each triangle's mesh
+    const float *tri_albedo;   // n_tris x rgb (the mesh's material colour; textures are not sampled on the device)
     float *out_rgb;
     float *out_gbuf;
 };
@@ -65,6 +70,8 @@ __global__ __launch_bounds__(256) void k_scene_frame(SceneArgs a)
     float t_best = inf;
     int gid = -1;
     float n[3] = { 0.0f, 0.0f, 0.0f }, ph[3] = { 0.0f, 0.0f, 0.0f };
+    float alb[3] = { 0.0f, 0.0f, 0.0f };
+    float emit = 0.0f;
     for (int k = 0; k < a.n_geoms; k++) {
         const SvgfSceneGeom &g = a.geoms[k];
         float qo[3], qd[3];
@@ -108,18 +115,52 @@ __global__ __launch_bounds__(256) void k_scene_frame(SceneArgs a)
         const float dv0 = o[0] - pw[0], dv1 = o[1] - pw[1], dv2 = o[2] - pw[2];
         const float tw = sqrtf((dv0 * dv0 + dv1 * dv1) + dv2 * dv2);        // t is measured in world space
         if (hit && (tw > 1e-4f) && (tw < t_best)) {
-            t_best = tw; gid = k;
+            t_best = tw; gid = a.geom_ids ? a.geom_ids[k] : k;
             n[0] = nw[0]; n[1] = nw[1]; n[2] = nw[2];
             ph[0] = pw[0]; ph[1] = pw[1]; ph[2] = pw[2];
+            alb[0] = g.albedo[0]; alb[1] = g.albedo[1]; alb[2] = g.albedo[2]; emit = g.emittance;
+        }
+    }
+    // Triangle meshes: the nearest triangle of the whole scene (the reference walks one BVH over all of them and keeps the hit
+    // if it belongs to the mesh being tested, src/pathtrace.cu:241-252), glm::intersectRayTriangle (gtx/intersect.inl:37-74),
+    // normal = n0 * b.x + n1 * b.y + n2 * (1 - b.x - b.y) normalised (Triangle::Intersect, src/sceneStructs.h:168-172, sic)
+    {
+        int best = -1;
+        float bt = t_best, bbx = 0.0f, bby = 0.0f;
+        for (int i = 0; i < a.n_tris; i++) {
+            const float *T = a.tris + 24 * (size_t)i;
+            const float e1[3] = { T[8] - T[0], T[9] - T[1], T[10] - T[2] }, e2[3] = { T[16] - T[0], T[17] - T[1], T[18] - T[2] };
+            const float pv[3] = { d[1] * e2[2] - e2[1] * d[2], d[2] * e2[0] - e2[2] * d[0], d[0] * e2[1] - e2[0] * d[1] };
+            const float det = (e1[0] * pv[0] + e1[1] * pv[1]) + e1[2] * pv[2];
+            if (det < 1.1920929e-7f) continue;
+            const float f = 1.0f / det;
+            const float sv[3] = { o[0] - T[0], o[1] - T[1], o[2] - T[2] };
+            const float bx = f * ((sv[0] * pv[0] + sv[1] * pv[1]) + sv[2] * pv[2]);
+            if (bx < 0.0f || bx > 1.0f) continue;
+            const float q[3] = { sv[1] * e1[2] - e1[1] * sv[2], sv[2] * e1[0] - e1[2] * sv[0], sv[0] * e1[1] - e1[0] * sv[1] };
+            const float by = f * ((d[0] * q[0] + d[1] * q[1]) + d[2] * q[2]);
+            if (by < 0.0f || by + bx > 1.0f) continue;
+            const float t = f * ((e2[0] * q[0] + e2[1] * q[1]) + e2[2] * q[2]);
+            if (t > 0.0f && t < bt) { bt = t; best = i; bbx = bx; bby = by; }
+        }
+        if (best >= 0) {
+            const float *T = a.tris + 24 * (size_t)best;
+            const float w2 = 1.0f - bbx - bby;
+            for (int c = 0; c < 3; c++) {
+                n[c] = (T[3 + c] * bbx + T[11 + c] * bby) + T[19 + c] * w2;
+                ph[c] = o[c] + bt * d[c];
+                alb[c] = a.tri_albedo[3 * (size_t)best + c];
+            }
+            normalise3(n);
+            emit = 0.0f;
+            gid = a.tri_ids[best];
+            t_best = bt;
         }
     }
 
     const bool miss = gid < 0;
     float pos[3];
     for (int c = 0; c < 3; c++) pos[c] = miss ? (o[c] + -1.0f * d[c]) : ph[c];      // t = -1 on a miss (src/pathtrace.cu:318)
-    float alb[3] = { 0.0f, 0.0f, 0.0f };
-    float emit = 0.0f;
-    if (!miss) { alb[0] = a.geoms[gid].albedo[0]; alb[1] = a.geoms[gid].albedo[1]; alb[2] = a.geoms[gid].albedo[2]; emit = a.geoms[gid].emittance; }
 
     float tl[3];
     for (int c = 0; c < 3; c++) tl[c] = a.light[c] - pos[c];
@@ -150,35 +191,59 @@ __global__ __launch_bounds__(256) void k_scene_frame(SceneArgs a)
 
 }  // namespace
 
-extern "C" int svgf_scene_render(int device, void *out_rgb_dev, void *out_gbuffer_dev, int width, int height,
-                                 const SvgfCamera *cam, const SvgfSynthParams *sp, const SvgfSceneGeom *geoms, int n_geoms,
-                                 const float light[3], void *stream)
+extern "C" int svgf_scene_render_mesh(int device, void *out_rgb_dev, void *out_gbuffer_dev, int width, int height,
+                                      const SvgfCamera *cam, const SvgfSynthParams *sp, const SvgfSceneGeom *geoms, int n_geoms,
+                                      const int *geom_ids, const float *tris, const int *tri_ids, const float *tri_albedo, int n_tris,
+                                      const float light[3], void *stream)
 {
-    if (!out_rgb_dev || !out_gbuffer_dev || !cam || !sp || !geoms || !light || width <= 0 || height <= 0) return SVGF_ERR_INVALID_ARG;
-    if (n_geoms < 0 || n_geoms > SVGF_SCENE_MAX_GEOMS) return SVGF_ERR_INVALID_ARG;
+    if (!out_rgb_dev || !out_gbuffer_dev || !cam || !sp || !light || width <= 0 || height <= 0) return SVGF_ERR_INVALID_ARG;
+    if (n_geoms < 0 || n_geoms > SVGF_SCENE_MAX_GEOMS || (n_geoms > 0 && !geoms)) return SVGF_ERR_INVALID_ARG;
+    if (n_tris < 0 || n_tris > SVGF_SCENE_MAX_TRIS || (n_tris > 0 && (!tris || !tri_ids || !tri_albedo))) return SVGF_ERR_INVALID_ARG;
     if ((long long)width * height >= (1LL << 31) / 16) return SVGF_ERR_UNSUPPORTED;
     SvgfDeviceGuard dev_guard(device);
     if (!dev_guard.ok) return SVGF_ERR_NO_DEVICE;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    SvgfSceneGeom *d_geoms = nullptr;
-    const size_t bytes = sizeof(SvgfSceneGeom) * (size_t)(n_geoms > 0 ? n_geoms : 1);
-    if (hipMallocAsync(reinterpret_cast<void **>(&d_geoms), bytes, s) != hipSuccess) return SVGF_ERR_OOM;
-    if (n_geoms > 0 && hipMemcpyAsync(d_geoms, geoms, sizeof(SvgfSceneGeom) * (size_t)n_geoms, hipMemcpyHostToDevice, s) != hipSuccess) {
-        (void)hipFreeAsync(d_geoms, s);
-        return SVGF_ERR_HIP;
+    // one staging allocation: [geoms | geom_ids | tris | tri_ids | tri_albedo]
+    const size_t b_g = sizeof(SvgfSceneGeom) * (size_t)(n_geoms > 0 ? n_geoms : 1), b_gi = sizeof(int) * (size_t)(n_geoms > 0 ? n_geoms : 1);
+    const size_t b_t = sizeof(float) * 24 * (size_t)(n_tris > 0 ? n_tris : 1), b_ti = sizeof(int) * (size_t)(n_tris > 0 ? n_tris : 1);
+    const size_t b_ta = sizeof(float) * 3 * (size_t)(n_tris > 0 ? n_tris : 1);
+    char *d = nullptr;
+    if (hipMallocAsync(reinterpret_cast<void **>(&d), b_g + b_gi + b_t + b_ti + b_ta, s) != hipSuccess) return SVGF_ERR_OOM;
+    bool ok = true;
+    if (n_geoms > 0) ok = ok && hipMemcpyAsync(d, geoms, sizeof(SvgfSceneGeom) * (size_t)n_geoms, hipMemcpyHostToDevice, s) == hipSuccess;
+    if (n_geoms > 0 && geom_ids) ok = ok && hipMemcpyAsync(d + b_g, geom_ids, sizeof(int) * (size_t)n_geoms, hipMemcpyHostToDevice, s) == hipSuccess;
+    if (n_tris > 0) {
+        ok = ok && hipMemcpyAsync(d + b_g + b_gi, tris, sizeof(float) * 24 * (size_t)n_tris, hipMemcpyHostToDevice, s) == hipSuccess;
+        ok = ok && hipMemcpyAsync(d + b_g + b_gi + b_t, tri_ids, sizeof(int) * (size_t)n_tris, hipMemcpyHostToDevice, s) == hipSuccess;
+        ok = ok && hipMemcpyAsync(d + b_g + b_gi + b_t + b_ti, tri_albedo, sizeof(float) * 3 * (size_t)n_tris, hipMemcpyHostToDevice, s) == hipSuccess;
     }
+    if (!ok) { (void)hipFreeAsync(d, s); return SVGF_ERR_HIP; }
     SceneArgs a;
     for (int c = 0; c < 3; c++) { a.right[c] = cam->right[c]; a.up[c] = cam->up[c]; a.view[c] = cam->view[c]; a.o[c] = cam->position[c]; a.light[c] = light[c]; }
     a.plx = sp->pixel_length[0]; a.ply = sp->pixel_length[1];
     a.cx = (float)(width * 0.5 - 0.5); a.cy = (float)(height * 0.5 - 0.5);
     a.noise = sp->noise; a.fireflies = sp->fireflies; a.chroma_amp = 0.1f * sp->noise;
     a.W = width; a.H = height; a.frame = sp->frame; a.seed = sp->seed; a.n_geoms = n_geoms;
-    a.geoms = d_geoms;
+    a.geoms = reinterpret_cast<const SvgfSceneGeom *>(d);
+    a.geom_ids = (n_geoms > 0 && geom_ids) ? reinterpret_cast<const int *>(d + b_g) : nullptr;
+    a.n_tris = n_tris;
+    a.tris = reinterpret_cast<const float *>(d + b_g + b_gi);
+    a.tri_ids = reinterpret_cast<const int *>(d + b_g + b_gi + b_t);
+    a.tri_albedo = reinterpret_cast<const float *>(d + b_g + b_gi + b_t + b_ti);
     a.out_rgb = static_cast<float *>(out_rgb_dev);
     a.out_gbuf = static_cast<float *>(out_gbuffer_dev);
     const int n = width * height;
     hipLaunchKernelGGL(k_scene_frame, dim3((n + 255) / 256), dim3(256), 0, s, a);
     const hipError_t e = hipGetLastError();
-    (void)hipFreeAsync(d_geoms, s);
+    (void)hipFreeAsync(d, s);
     return e == hipSuccess ? SVGF_OK : SVGF_ERR_HIP;
+}
+
+extern "C" int svgf_scene_render(int device, void *out_rgb_dev, void *out_gbuffer_dev, int width, int height,
+                                 const SvgfCamera *cam, const SvgfSynthParams *sp, const SvgfSceneGeom *geoms, int n_geoms,
+                                 const float light[3], void *stream)
+{
+    if (!geoms) return SVGF_ERR_INVALID_ARG;
+    return svgf_scene_render_mesh(device, out_rgb_dev, out_gbuffer_dev, width, height, cam, sp, geoms, n_geoms, nullptr, nullptr, nullptr,
+                                  nullptr, 0, light, stream);
 }

@@ -224,6 +224,17 @@ typedef struct SvgfSceneGeom {
 int svgf_scene_render(int device, void *out_rgb_dev, void *out_gbuffer_dev, int width, int height,
                       const SvgfCamera *cam, const SvgfSynthParams *sp, const SvgfSceneGeom *geoms, int n_geoms,
                       const float light[3], void *stream);
+/* The same with the scene's triangle meshes (Scene::loadMesh's world-space triangles, src/scene.cpp:234-311; host arrays, same
+ * lifetime rule as `geoms`): `tris` = n_tris x 3 vertices x {pos[3], normal[3], uv[2]}, `tri_ids` = the object index written as
+ * geomId for each triangle, `tri_albedo` = n_tris x rgb (the mesh's material colour: textures are not sampled on the device),
+ * `geom_ids` = the object index written as geomId for each primitive (NULL: its position in `geoms`).  First hit as the
+ * reference's computeIntersection (src/pathtrace.cu:211-276): nearest of primitives and the nearest triangle of the scene
+ * (glm::intersectRayTriangle), mesh normal interpolated with Triangle::Intersect's corner weights (src/sceneStructs.h:168-172). */
+#define SVGF_SCENE_MAX_TRIS (1 << 20)
+int svgf_scene_render_mesh(int device, void *out_rgb_dev, void *out_gbuffer_dev, int width, int height,
+                           const SvgfCamera *cam, const SvgfSynthParams *sp, const SvgfSceneGeom *geoms, int n_geoms,
+                           const int *geom_ids, const float *tris, const int *tri_ids, const float *tri_albedo, int n_tris,
+                           const float light[3], void *stream);
 
 /* ---- "next" row f2: the step right after denoise() ------------------------------------------------
  * svgf_display_pack: reference sendTwoImagesToPBO (src/pathtrace.cu:45-77, launched at :446): `left` (the 1-spp

@@ -17,7 +17,7 @@ import pytest
 from conftest import ROOT, relerr, replay
 
 DIR = os.path.join(ROOT, "tests", "golden", "ref_scenes")
-CASES = sorted(f[:-4] for f in os.listdir(DIR) if f.endswith(".npz"))
+CASES = sorted(f[:-4] for f in os.listdir(DIR) if f.endswith(".npz") and not f.endswith("_producer_inputs.npz"))
 
 
 def test_fixtures_present():
@@ -219,3 +219,45 @@ def test_first_hit_with_meshes_matches_reference_gbuffer(pkg, name, scene):
         miss = same & (ref["geomId"] < 0)
         if miss.any():
             assert np.abs(gb["position"][miss] - ref["position"][miss]).max() <= 1e-5          # origin - direction (:317)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,scene", [("cornell96_static", "cornell"), ("cornell128x72_moving", "cornell"), ("room128x72_static_sepcolor", "room")])
+def test_device_producer_with_meshes_matches_reference_gbuffer(pkg, name, scene):
+    """svgf_scene_render_mesh — the device-side producer with the scene's primitives AND triangle meshes
+    (tests/golden/ref_scenes/<scene>_producer_inputs.npz: scene.geom_array + mesh.scene_triangles of the reference's files) —
+    against the G-buffer the reference's own path tracer wrote for the same camera: geomId, world position, normal (mesh
+    normals with the reference's corner weights), albedo of untextured objects; then the produced frame goes through the
+    denoiser like any other."""
+    import torch
+    z = np.load(os.path.join(DIR, name + ".npz"))
+    pi = np.load(os.path.join(DIR, scene + "_producer_inputs.npz"))
+    W, H = int(z["W"]), int(z["H"])
+    rgb = torch.empty((H, W, 3), dtype=torch.float32, device="cuda")
+    gbt = torch.empty((H * W * 52,), dtype=torch.uint8, device="cuda")
+    den = pkg.Denoiser(W, H, 0)
+    p = pkg.reference_defaults().set(temporal_enable=1, spatial_enable=1)
+    for f in range(z["cams"].shape[0]):
+        c = z["cams"][f]
+        cam = dict(right=c[0:3].astype(np.float32), up=c[3:6].astype(np.float32), view=c[6:9].astype(np.float32),
+                   position=c[9:12].astype(np.float32), fovy_deg=float(pi["fovy"]))
+        pkg.binding.scene_render_mesh(rgb, gbt, W, H, cam, pi["geoms"], pi["geom_ids"], pi["tris"], pi["tri_ids"], pi["tri_albedo"], frame=f)
+        gb = gbt.cpu().numpy().view(pkg.synth.GBUFFER_DTYPE).reshape(H, W)
+        ref = z["gbuffer"][f]
+        same = gb["geomId"] == ref["geomId"]
+        assert same.mean() >= 0.995, f"{name} frame {f}: geomId agrees on {same.mean():.4f}"
+        hit = same & (ref["geomId"] >= 0)
+        assert np.abs(gb["position"][hit] - ref["position"][hit]).max() <= 1e-3
+        assert np.abs(gb["normal"][hit] - ref["normal"][hit]).max() <= 1e-3
+        plain = hit & ~np.isin(ref["geomId"], pi["textured_objects"])
+        assert np.abs(gb["albedo"][plain] - ref["albedo"][plain]).max() <= 1e-6
+        miss = same & (ref["geomId"] < 0)
+        if miss.any():
+            assert np.abs(gb["position"][miss] - ref["position"][miss]).max() <= 1e-5
+        col = rgb.cpu().numpy()
+        assert np.isfinite(col).all() and (col[gb["geomId"] < 0] == 0).all()
+        out = torch.empty((H, W, 3), dtype=torch.float32, device="cuda")
+        den.denoise(out, rgb, gbt, cam, p)
+        torch.cuda.synchronize()
+        assert np.isfinite(out.cpu().numpy()).all()
+    den.free()
