@@ -19,9 +19,15 @@ d = json.load(open(p))
 d["per_level_bytes_per_pixel"] = lv
 d["mean_bytes_per_pixel_per_launch"] = round(tot / 5, 1)
 d["mean_bytes_per_launch"] = int(tot / 5 * px)
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402  (kernel_sources_sha16: the fingerprint bench.py checks before it reports this record)
+d["kernel_sources_sha16"] = bench.kernel_sources_sha16()
+d["source_file"] = os.path.basename(sys.argv[1]) if len(sys.argv) > 1 else ""
+d["why_above_algorithmic"] = ("4 halo rows per 17-row segment (x1.24 on the 40 B/px read) and 2*S halo columns per strip; +4 B/px written by the levels "
+                              "that feed a step-16/32 level its 4-byte variance plane (which saves those levels ~24 B/px of 4-B gathers from 16-B texels)")
 d["_comment"] = ("HBM-side traffic of the a-trous kernels (default path: k_atrous_lane for steps 2-8, k_atrous_strip for 16-32) from rocprofv3 "
                  "PMC, collected as MI355X_MICROARCH.md prescribes: FETCH_SIZE and WRITE_SIZE in separate --pmc passes "
-                 "(profiles/r01_pmc_hbm_final.txt), KiB units, FETCH_SIZE doubled (gfx950 tallies 128-B read requests at 64 B). "
-                 "Bytes per pixel per launch, 1920x1080.")
+                 "(profiles/r02_pmc_hbm.txt), KiB units, FETCH_SIZE doubled (gfx950 tallies 128-B read requests at 64 B). "
+                 "Bytes per pixel per launch, 1920x1080.  Reported by bench.py only while kernel_sources_sha16 matches the sources.")
 json.dump(d, open(p, "w"), indent=2)
 print(json.dumps(lv), d["mean_bytes_per_pixel_per_launch"], d["mean_bytes_per_launch"])
