@@ -124,7 +124,7 @@ def load_library(path: str | None = None):
     lib.svgf_scene_render.argtypes = [ip, vp, vp, ip, ip, C.POINTER(SvgfCamera), C.POINTER(SvgfSynthParams), vp, ip,
                                       C.POINTER(C.c_float), vp]
     lib.svgf_scene_render_mesh.argtypes = [ip, vp, vp, ip, ip, C.POINTER(SvgfCamera), C.POINTER(SvgfSynthParams), vp, ip,
-                                           vp, vp, vp, vp, ip, C.POINTER(C.c_float), vp]
+                                           vp, vp, vp, vp, ip, vp, vp, vp, ip, C.POINTER(C.c_float), vp]
     lib.svgf_display_pack.argtypes = [ip, vp, vp, vp, ip, ip, vp]
     lib.svgf_save_png.argtypes = [C.c_char_p, vp, ip, ip, ip]
     if path == LIB_PATH:
@@ -313,7 +313,7 @@ def scene_render(out_rgb, out_gbuffer, width: int, height: int, camera, geoms: n
 
 
 def scene_render_mesh(out_rgb, out_gbuffer, width: int, height: int, camera, geoms: np.ndarray, geom_ids, tris, tri_ids, tri_albedo,
-                      frame: int, seed: int = 1, noise: float = 0.6, fireflies: float = 0.02, pixel_length=None, light=None,
+                      frame: int, tri_tex=None, textures=None, seed: int = 1, noise: float = 0.6, fireflies: float = 0.02, pixel_length=None, light=None,
                       device: int = 0, stream=None):
     """svgf_scene_render_mesh: primitives (`geoms`, geomId = geom_ids[k]) + world-space triangles (`tris` float32[n,3,8] =
     pos, normal, uv per corner; geomId = tri_ids[i]; albedo = tri_albedo[i]).  The caller must keep the arrays alive until
@@ -333,13 +333,28 @@ def scene_render_mesh(out_rgb, out_gbuffer, width: int, height: int, camera, geo
     tr = np.ascontiguousarray(tris, dtype=np.float32).reshape(-1, 24)
     ti = np.ascontiguousarray(tri_ids, dtype=np.int32)
     ta = np.ascontiguousarray(tri_albedo, dtype=np.float32).reshape(-1, 3)
+    # textures: list of uint8[h, w, 3]; tri_tex: index into that list per triangle, -1 = none
+    n_tex, tt, td, tx = 0, None, None, None
+    if textures is not None and len(textures) and tri_tex is not None:
+        n_tex = len(textures)
+        tt = np.ascontiguousarray(tri_tex, dtype=np.int32)
+        offs, blobs, o = [], [], 0
+        for t in textures:
+            t = np.ascontiguousarray(t, dtype=np.uint8)
+            offs += [o, t.shape[1], t.shape[0]]
+            blobs.append(t.reshape(-1))
+            o += t.size
+        td = np.array(offs, dtype=np.int32)
+        tx = np.concatenate(blobs)
     lp = _scene.light_position(geoms) if light is None else np.asarray(light, dtype=np.float32)
     larr = (C.c_float * 3)(float(lp[0]), float(lp[1]), float(lp[2]))
     s = None if stream is None else (stream if isinstance(stream, int) else stream.cuda_stream)
     rc = lib.svgf_scene_render_mesh(int(device), _ptr(out_rgb), _ptr(out_gbuffer), int(width), int(height), C.byref(cam), C.byref(sp),
                                     geoms.ctypes.data if len(geoms) else None, int(len(geoms)), gi.ctypes.data if len(gi) else None,
                                     tr.ctypes.data if len(tr) else None, ti.ctypes.data if len(ti) else None,
-                                    ta.ctypes.data if len(ta) else None, int(len(tr)), larr, s)
+                                    ta.ctypes.data if len(ta) else None, int(len(tr)),
+                                    tt.ctypes.data if n_tex else None, td.ctypes.data if n_tex else None, tx.ctypes.data if n_tex else None,
+                                    int(n_tex), larr, s)
     if rc != SVGF_OK:
         raise SvgfError(f"svgf_scene_render_mesh failed ({rc})")
     if stream is None:

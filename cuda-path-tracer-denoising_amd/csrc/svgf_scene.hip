@@ -27,7 +27,10 @@ struct SceneArgs {
     int n_tris;                // world-space triangles of the scene's meshes (Scene::loadMesh, src/scene.cpp:234-311)
     const float *tris;         // n_tris x 3 vertices x {pos3, normal3, uv2}
     const int *tri_ids;        // object index of each triangle's mesh
-    const float *tri_albedo;   // n_tris x rgb (the mesh's material colour; textures are not sampled on the device)
+    const float *tri_albedo;   // n_tris x rgb (the mesh's material colour)
+    const int *tri_tex;        // texture index per triangle, -1 = untextured (null: no textures)
+    const int *tex_desc;       // per texture {byte offset into tex, width, height}, 8-bit RGB rows top to bottom
+    const unsigned char *tex;
     float *out_rgb;
     float *out_gbuf;
 };
@@ -152,6 +155,15 @@ __global__ __launch_bounds__(256) void k_scene_frame(SceneArgs a)
                 alb[c] = a.tri_albedo[3 * (size_t)best + c];
             }
             normalise3(n);
+            const int tx = a.tri_tex ? a.tri_tex[best] : -1;
+            if (tx >= 0) {      // Texture::getColor (src/sceneStructs.h:208-219) at the interpolated uv (Triangle::Intersect :162-164)
+                const float u = (T[6] * w2 + T[14] * bbx) + T[22] * bby, v = (T[7] * w2 + T[15] * bbx) + T[23] * bby;
+                const int tw = a.tex_desc[3 * tx + 1], th = a.tex_desc[3 * tx + 2];
+                int X = (int)fminf(1.0f * (float)tw * u, 1.0f * (float)tw - 1.0f), Y = (int)fminf(1.0f * (float)th * (1.0f - v), 1.0f * (float)th - 1.0f);
+                X = X < 0 ? 0 : X; Y = Y < 0 ? 0 : Y;                          // (the reference indexes out of bounds here)
+                const unsigned char *px = a.tex + a.tex_desc[3 * tx] + 3 * ((size_t)Y * tw + X);
+                for (int c = 0; c < 3; c++) alb[c] = 0.003921568627f * (float)px[c];
+            }
             emit = 0.0f;
             gid = a.tri_ids[best];
             t_best = bt;
@@ -194,21 +206,31 @@ __global__ __launch_bounds__(256) void k_scene_frame(SceneArgs a)
 extern "C" int svgf_scene_render_mesh(int device, void *out_rgb_dev, void *out_gbuffer_dev, int width, int height,
                                       const SvgfCamera *cam, const SvgfSynthParams *sp, const SvgfSceneGeom *geoms, int n_geoms,
                                       const int *geom_ids, const float *tris, const int *tri_ids, const float *tri_albedo, int n_tris,
+                                      const int *tri_tex, const int *tex_desc, const unsigned char *tex_data, int n_tex,
                                       const float light[3], void *stream)
 {
     if (!out_rgb_dev || !out_gbuffer_dev || !cam || !sp || !light || width <= 0 || height <= 0) return SVGF_ERR_INVALID_ARG;
     if (n_geoms < 0 || n_geoms > SVGF_SCENE_MAX_GEOMS || (n_geoms > 0 && !geoms)) return SVGF_ERR_INVALID_ARG;
     if (n_tris < 0 || n_tris > SVGF_SCENE_MAX_TRIS || (n_tris > 0 && (!tris || !tri_ids || !tri_albedo))) return SVGF_ERR_INVALID_ARG;
+    if (n_tex < 0 || n_tex > 64 || (n_tex > 0 && (!tri_tex || !tex_desc || !tex_data || n_tris == 0))) return SVGF_ERR_INVALID_ARG;
+    size_t b_tex = 16;
+    for (int k = 0; k < n_tex; k++) {
+        if (tex_desc[3 * k] < 0 || tex_desc[3 * k + 1] <= 0 || tex_desc[3 * k + 2] <= 0) return SVGF_ERR_INVALID_ARG;
+        const size_t end = (size_t)tex_desc[3 * k] + (size_t)3 * tex_desc[3 * k + 1] * tex_desc[3 * k + 2];
+        if (end > b_tex) b_tex = end;
+    }
     if ((long long)width * height >= (1LL << 31) / 16) return SVGF_ERR_UNSUPPORTED;
     SvgfDeviceGuard dev_guard(device);
     if (!dev_guard.ok) return SVGF_ERR_NO_DEVICE;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    // one staging allocation: [geoms | geom_ids | tris | tri_ids | tri_albedo]
+    // one staging allocation: [geoms | geom_ids | tris | tri_ids | tri_albedo | tri_tex | tex_desc | tex]
     const size_t b_g = sizeof(SvgfSceneGeom) * (size_t)(n_geoms > 0 ? n_geoms : 1), b_gi = sizeof(int) * (size_t)(n_geoms > 0 ? n_geoms : 1);
     const size_t b_t = sizeof(float) * 24 * (size_t)(n_tris > 0 ? n_tris : 1), b_ti = sizeof(int) * (size_t)(n_tris > 0 ? n_tris : 1);
     const size_t b_ta = sizeof(float) * 3 * (size_t)(n_tris > 0 ? n_tris : 1);
+    const size_t b_tt = b_ti, b_td = sizeof(int) * 3 * (size_t)(n_tex > 0 ? n_tex : 1);
+    const size_t o_tt = b_g + b_gi + b_t + b_ti + b_ta, o_td = o_tt + b_tt, o_tex = (o_td + b_td + 15) & ~(size_t)15;
     char *d = nullptr;
-    if (hipMallocAsync(reinterpret_cast<void **>(&d), b_g + b_gi + b_t + b_ti + b_ta, s) != hipSuccess) return SVGF_ERR_OOM;
+    if (hipMallocAsync(reinterpret_cast<void **>(&d), o_tex + b_tex, s) != hipSuccess) return SVGF_ERR_OOM;
     bool ok = true;
     if (n_geoms > 0) ok = ok && hipMemcpyAsync(d, geoms, sizeof(SvgfSceneGeom) * (size_t)n_geoms, hipMemcpyHostToDevice, s) == hipSuccess;
     if (n_geoms > 0 && geom_ids) ok = ok && hipMemcpyAsync(d + b_g, geom_ids, sizeof(int) * (size_t)n_geoms, hipMemcpyHostToDevice, s) == hipSuccess;
@@ -216,6 +238,11 @@ extern "C" int svgf_scene_render_mesh(int device, void *out_rgb_dev, void *out_g
         ok = ok && hipMemcpyAsync(d + b_g + b_gi, tris, sizeof(float) * 24 * (size_t)n_tris, hipMemcpyHostToDevice, s) == hipSuccess;
         ok = ok && hipMemcpyAsync(d + b_g + b_gi + b_t, tri_ids, sizeof(int) * (size_t)n_tris, hipMemcpyHostToDevice, s) == hipSuccess;
         ok = ok && hipMemcpyAsync(d + b_g + b_gi + b_t + b_ti, tri_albedo, sizeof(float) * 3 * (size_t)n_tris, hipMemcpyHostToDevice, s) == hipSuccess;
+    }
+    if (n_tex > 0) {
+        ok = ok && hipMemcpyAsync(d + o_tt, tri_tex, sizeof(int) * (size_t)n_tris, hipMemcpyHostToDevice, s) == hipSuccess;
+        ok = ok && hipMemcpyAsync(d + o_td, tex_desc, sizeof(int) * 3 * (size_t)n_tex, hipMemcpyHostToDevice, s) == hipSuccess;
+        ok = ok && hipMemcpyAsync(d + o_tex, tex_data, b_tex, hipMemcpyHostToDevice, s) == hipSuccess;
     }
     if (!ok) { (void)hipFreeAsync(d, s); return SVGF_ERR_HIP; }
     SceneArgs a;
@@ -230,6 +257,9 @@ extern "C" int svgf_scene_render_mesh(int device, void *out_rgb_dev, void *out_g
     a.tris = reinterpret_cast<const float *>(d + b_g + b_gi);
     a.tri_ids = reinterpret_cast<const int *>(d + b_g + b_gi + b_t);
     a.tri_albedo = reinterpret_cast<const float *>(d + b_g + b_gi + b_t + b_ti);
+    a.tri_tex = n_tex > 0 ? reinterpret_cast<const int *>(d + o_tt) : nullptr;
+    a.tex_desc = reinterpret_cast<const int *>(d + o_td);
+    a.tex = reinterpret_cast<const unsigned char *>(d + o_tex);
     a.out_rgb = static_cast<float *>(out_rgb_dev);
     a.out_gbuf = static_cast<float *>(out_gbuffer_dev);
     const int n = width * height;
@@ -245,5 +275,5 @@ extern "C" int svgf_scene_render(int device, void *out_rgb_dev, void *out_gbuffe
 {
     if (!geoms) return SVGF_ERR_INVALID_ARG;
     return svgf_scene_render_mesh(device, out_rgb_dev, out_gbuffer_dev, width, height, cam, sp, geoms, n_geoms, nullptr, nullptr, nullptr,
-                                  nullptr, 0, light, stream);
+                                  nullptr, 0, nullptr, nullptr, nullptr, 0, light, stream);
 }

@@ -226,14 +226,17 @@ int svgf_scene_render(int device, void *out_rgb_dev, void *out_gbuffer_dev, int 
                       const float light[3], void *stream);
 /* The same with the scene's triangle meshes (Scene::loadMesh's world-space triangles, src/scene.cpp:234-311; host arrays, same
  * lifetime rule as `geoms`): `tris` = n_tris x 3 vertices x {pos[3], normal[3], uv[2]}, `tri_ids` = the object index written as
- * geomId for each triangle, `tri_albedo` = n_tris x rgb (the mesh's material colour: textures are not sampled on the device),
- * `geom_ids` = the object index written as geomId for each primitive (NULL: its position in `geoms`).  First hit as the
+ * geomId for each triangle, `tri_albedo` = n_tris x rgb (the mesh's material colour), `geom_ids` = the object index written
+ * as geomId for each primitive (NULL: its position in `geoms`).  Textures (n_tex may be 0): `tex_data` = 8-bit RGB images, rows
+ * top to bottom, `tex_desc` = n_tex x {byte offset into tex_data, width, height}, `tri_tex` = texture index per triangle or -1;
+ * a textured triangle's albedo is Texture::getColor at the interpolated uv (src/sceneStructs.h:208-219, :162-164).  First hit as the
  * reference's computeIntersection (src/pathtrace.cu:211-276): nearest of primitives and the nearest triangle of the scene
  * (glm::intersectRayTriangle), mesh normal interpolated with Triangle::Intersect's corner weights (src/sceneStructs.h:168-172). */
 #define SVGF_SCENE_MAX_TRIS (1 << 20)
 int svgf_scene_render_mesh(int device, void *out_rgb_dev, void *out_gbuffer_dev, int width, int height,
                            const SvgfCamera *cam, const SvgfSynthParams *sp, const SvgfSceneGeom *geoms, int n_geoms,
                            const int *geom_ids, const float *tris, const int *tri_ids, const float *tri_albedo, int n_tris,
+                           const int *tri_tex, const int *tex_desc, const unsigned char *tex_data, int n_tex,
                            const float light[3], void *stream);
 
 /* ---- "next" row f2: the step right after denoise() ------------------------------------------------

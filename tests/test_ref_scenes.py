@@ -241,7 +241,9 @@ def test_device_producer_with_meshes_matches_reference_gbuffer(pkg, name, scene)
         c = z["cams"][f]
         cam = dict(right=c[0:3].astype(np.float32), up=c[3:6].astype(np.float32), view=c[6:9].astype(np.float32),
                    position=c[9:12].astype(np.float32), fovy_deg=float(pi["fovy"]))
-        pkg.binding.scene_render_mesh(rgb, gbt, W, H, cam, pi["geoms"], pi["geom_ids"], pi["tris"], pi["tri_ids"], pi["tri_albedo"], frame=f)
+        textures = [pi[k] for k in sorted(pi.files) if k.startswith("texture") and k != "textured_objects"] if "tri_tex" in pi.files else None
+        pkg.binding.scene_render_mesh(rgb, gbt, W, H, cam, pi["geoms"], pi["geom_ids"], pi["tris"], pi["tri_ids"], pi["tri_albedo"], frame=f,
+                                      tri_tex=pi["tri_tex"] if textures else None, textures=textures)
         gb = gbt.cpu().numpy().view(pkg.synth.GBUFFER_DTYPE).reshape(H, W)
         ref = z["gbuffer"][f]
         same = gb["geomId"] == ref["geomId"]
@@ -251,6 +253,9 @@ def test_device_producer_with_meshes_matches_reference_gbuffer(pkg, name, scene)
         assert np.abs(gb["normal"][hit] - ref["normal"][hit]).max() <= 1e-3
         plain = hit & ~np.isin(ref["geomId"], pi["textured_objects"])
         assert np.abs(gb["albedo"][plain] - ref["albedo"][plain]).max() <= 1e-6
+        if textures:            # textured mesh: Texture::getColor at the interpolated uv; PIL and stb decode the JPEG within 2 levels
+            tex_px = hit & np.isin(ref["geomId"], pi["textured_objects"])
+            assert tex_px.any() and np.abs(gb["albedo"][tex_px] - ref["albedo"][tex_px]).max() <= 2.01 / 255.0
         miss = same & (ref["geomId"] < 0)
         if miss.any():
             assert np.abs(gb["position"][miss] - ref["position"][miss]).max() <= 1e-5
