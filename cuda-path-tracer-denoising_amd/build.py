@@ -81,5 +81,8 @@ def build_reference(force: bool = False) -> str | None:
         return None
     if force and os.path.exists(out):
         os.remove(out)
-    _run(["make", "-s", "-C", os.path.join(ORACLE_DIR, "ref")])
-    return out if os.path.exists(out) else None
+    _run(["make", "-s", "-C", os.path.join(ORACLE_DIR, "ref")])       # raises with make's output when the recipe fails
+    scenes = os.path.join(ORACLE_DIR, "_ref", "scenes")
+    if not os.path.exists(out) or not os.path.isdir(scenes):
+        raise RuntimeError(f"reference build: make succeeded but {out} or {scenes} is missing")
+    return out

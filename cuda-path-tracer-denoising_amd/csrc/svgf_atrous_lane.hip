@@ -372,6 +372,24 @@ __global__ __launch_bounds__(NT) void k_atrous_lane(AtrousArgs a, LaneGeom gm)
             if (it == 0 && lgroup >= 1) loader_issue(lgroup);
             if ((it + 1) % kLoaderGroups == lgroup) loader_commit(it + 1);
             else if (it % kLoaderGroups == lgroup) loader_issue(it + kLoaderGroups);
+#ifdef SVGF_LANE_LOADER_BUSY
+            // occupancy experiment (tools/experiments/exp_third_wave.sh): the loader wave issues SVGF_LANE_LOADER_BUSY x
+            // {8 packed, 6 plain, 2 transcendental} VALU per iteration on private registers — ~a tap row's mix — to see
+            // what a THIRD computing wave per SIMD costs the two compute waves
+            {
+                float b0f = (float)it, b1f = 1.0f, b2f = 0.5f, b3f = 0.25f;
+                v2f pa = v2f{b0f, b1f}, pb = v2f{b2f, b3f}, pc = v2f{1.0f, 1.0f};
+#pragma unroll 1
+                for (int k = 0; k < SVGF_LANE_LOADER_BUSY; k++) {
+                    asm volatile("v_pk_fma_f32 %0, %1, %2, %0\n v_pk_fma_f32 %1, %0, %2, %1\n v_pk_fma_f32 %0, %1, %2, %0\n v_pk_fma_f32 %1, %0, %2, %1\n"
+                                 "v_pk_fma_f32 %0, %1, %2, %0\n v_pk_fma_f32 %1, %0, %2, %1\n v_pk_fma_f32 %0, %1, %2, %0\n v_pk_fma_f32 %1, %0, %2, %1\n"
+                                 "v_fma_f32 %3, %4, %5, %3\n v_fma_f32 %4, %3, %5, %4\n v_fma_f32 %3, %4, %5, %3\n v_fma_f32 %4, %3, %5, %4\n v_fma_f32 %3, %4, %5, %3\n v_fma_f32 %4, %3, %5, %4\n"
+                                 "v_exp_f32 %5, %5\n v_sqrt_f32 %5, %5\n"
+                                 : "+v"(pa), "+v"(pb), "+v"(pc), "+v"(b0f), "+v"(b1f), "+v"(b2f));
+                }
+                if (b0f + pa.x == 12345.678f) *nan_seen = 2;      // keeps the chain alive
+            }
+#endif
             stamp(5);
             __syncthreads();
             stamp(6);
