@@ -372,24 +372,6 @@ __global__ __launch_bounds__(NT) void k_atrous_lane(AtrousArgs a, LaneGeom gm)
             if (it == 0 && lgroup >= 1) loader_issue(lgroup);
             if ((it + 1) % kLoaderGroups == lgroup) loader_commit(it + 1);
             else if (it % kLoaderGroups == lgroup) loader_issue(it + kLoaderGroups);
-#ifdef SVGF_LANE_LOADER_BUSY
-            // occupancy experiment (tools/experiments/exp_third_wave.sh): the loader wave issues SVGF_LANE_LOADER_BUSY x
-            // {8 packed, 6 plain, 2 transcendental} VALU per iteration on private registers — ~a tap row's mix — to see
-            // what a THIRD computing wave per SIMD costs the two compute waves
-            {
-                float b0f = (float)it, b1f = 1.0f, b2f = 0.5f, b3f = 0.25f;
-                v2f pa = v2f{b0f, b1f}, pb = v2f{b2f, b3f}, pc = v2f{1.0f, 1.0f};
-#pragma unroll 1
-                for (int k = 0; k < SVGF_LANE_LOADER_BUSY; k++) {
-                    asm volatile("v_pk_fma_f32 %0, %1, %2, %0\n v_pk_fma_f32 %1, %0, %2, %1\n v_pk_fma_f32 %0, %1, %2, %0\n v_pk_fma_f32 %1, %0, %2, %1\n"
-                                 "v_pk_fma_f32 %0, %1, %2, %0\n v_pk_fma_f32 %1, %0, %2, %1\n v_pk_fma_f32 %0, %1, %2, %0\n v_pk_fma_f32 %1, %0, %2, %1\n"
-                                 "v_fma_f32 %3, %4, %5, %3\n v_fma_f32 %4, %3, %5, %4\n v_fma_f32 %3, %4, %5, %3\n v_fma_f32 %4, %3, %5, %4\n v_fma_f32 %3, %4, %5, %3\n v_fma_f32 %4, %3, %5, %4\n"
-                                 "v_exp_f32 %5, %5\n v_sqrt_f32 %5, %5\n"
-                                 : "+v"(pa), "+v"(pb), "+v"(pc), "+v"(b0f), "+v"(b1f), "+v"(b2f));
-                }
-                if (b0f + pa.x == 12345.678f) *nan_seen = 2;      // keeps the chain alive
-            }
-#endif
             stamp(5);
             __syncthreads();
             stamp(6);
@@ -406,7 +388,24 @@ __global__ __launch_bounds__(NT) void k_atrous_lane(AtrousArgs a, LaneGeom gm)
     const int xi = xph + S * mcol;                  // staged pixel column
     const int x = x0 - 2 * S + xi;                  // image column
     const bool out_lane = (lane >= 2) && (lane < 2 + LOUT) && (x < W);
-    const float kn = gm.kn, kx = gm.kx;
+    // An SGPR or literal source makes a VOP3 occupy the VALU as long as a packed instruction does (tools/ubench6.hip: 3.0
+    // cycles per SIMD against 1.7 with three waves, 4.5 against 2.5 with two): the two slopes and the five distinct values of
+    // -log2 h of the forward / own-row taps live in VGPRs (profiles/r03_ab_lane_operands.log: -1 % per level).
+    float kn = gm.kn, kx = gm.kx;
+    asm volatile("" : "+v"(kn), "+v"(kx));
+#ifndef SVGF_LANE_NO_VCONST
+    float hc_a = 1.4150374992788437f + 2.0f, hc_b = 4.0f, hc_c = 1.4150374992788437f + 4.0f, hc_d = 6.0f, hc_e = 8.0f;
+    asm volatile("" : "+v"(hc_a), "+v"(hc_b), "+v"(hc_c), "+v"(hc_d), "+v"(hc_e));
+    // -log2 h of tap (io, j) for j = 0, 1, 2 and |io| <= 2 (never the centre)
+    auto nlh = [&](int io, int j) -> float {
+        const int ai = io < 0 ? -io : io;
+        const int code = (ai == 0 ? 0 : (ai == 1 ? 1 : 2)) + (j == 0 ? 0 : (j == 1 ? 1 : 2));      // 1.415 -> 0, 2 -> 1, 4 -> 2; sums 1 .. 4
+        return (ai == 0 && j == 1) || (ai == 1 && j == 0) ? hc_a : (code == 2 && ai != 0 && j != 0) ? hc_b
+             : ((ai == 0 && j == 2) || (ai == 2 && j == 0)) ? hc_c : (code == 3) ? hc_d : hc_e;
+    };
+#else
+    auto nlh = [&](int io, int j) -> float { return neg_log2_binom(io) + neg_log2_binom(j); };
+#endif
     // base of the lane's tap window: record of column mcol-2, so that tap i = 0..4 (offset i-2) sits at +i*PXB and every
     // address is base + non-negative immediate (the ds_read offset field is unsigned)
     const char *colbase = smem + (xph * MP + mcol - 2) * PXB;
@@ -464,7 +463,11 @@ __global__ __launch_bounds__(NT) void k_atrous_lane(AtrousArgs a, LaneGeom gm)
 #pragma unroll
         for (int i = 0; i < 5; i++) {
             r.C[i] = *reinterpret_cast<const v4f *>(rowp + i * PXB + 32);
-            r.l[i] = reinterpret_cast<const v2f *>(rowp + i * PXB + 24)->x;      // {lum, pad}: 8-byte read
+            // luminance: the whole B slot as a b128 (conflict-free at the 48-byte lane stride; an 8-byte read of {lum, pad}
+            // is 2-way conflicted: lanes 16 apart share banks).  The variant without variance accumulators sits at the
+            // 168-VGPR edge of three waves per SIMD and keeps the narrow read.
+            if constexpr (HASVAR) r.l[i] = reinterpret_cast<const v4f *>(rowp + i * PXB + 16)->z;
+            else r.l[i] = reinterpret_cast<const v2f *>(rowp + i * PXB + 24)->x;
         }
     };
     auto load_geo = [&](GeoRow &r, int br) {
@@ -483,7 +486,8 @@ __global__ __launch_bounds__(NT) void k_atrous_lane(AtrousArgs a, LaneGeom gm)
             r.B[k] = *reinterpret_cast<const v4f *>(rowp + (k + 3) * PXB + 16);
             r.C[k] = *reinterpret_cast<const v4f *>(rowp + (k + 3) * PXB + 32);
             r.Cb[k] = *reinterpret_cast<const v4f *>(rowp + (1 - k) * PXB + 32);
-            r.l[k] = reinterpret_cast<const v2f *>(rowp + (1 - k) * PXB + 24)->x;
+            if constexpr (HASVAR) r.l[k] = reinterpret_cast<const v4f *>(rowp + (1 - k) * PXB + 16)->z;
+            else r.l[k] = reinterpret_cast<const v2f *>(rowp + (1 - k) * PXB + 24)->x;
         }
     };
     auto do_col = [&](Acc &acc, const ColRow &r, const float (&tt)[5], float lp, float kl) {
@@ -520,7 +524,7 @@ __global__ __launch_bounds__(NT) void k_atrous_lane(AtrousArgs a, LaneGeom gm)
         float e[5], w[5];
 #pragma unroll
         for (int i = 0; i < 5; i++) {
-            float t = fmaf(dn[i], kn, neg_log2_binom(i - 2) + neg_log2_binom(j));
+            float t = fmaf(dn[i], kn, nlh(i - 2, j));
             t = fmaf(dx[i], kx, t);
             F[i] = t;
             e[i] = fmaf(fabsf(lq[i] - lp), kl, t);
@@ -644,7 +648,7 @@ __global__ __launch_bounds__(NT) void k_atrous_lane(AtrousArgs a, LaneGeom gm)
             for (int k = 0; k < 2; k++) {
                 const v2f s2 = geo(r2.A[k], r2.B[k], c0, c1, c2);
                 const float dn = __builtin_amdgcn_sqrtf(s2.x), dx = __builtin_amdgcn_sqrtf(s2.y);
-                const float t = fmaf(dn, kn, neg_log2_binom(k + 1) + neg_log2_binom(0));
+                const float t = fmaf(dn, kn, nlh(k + 1, 0));
                 tf[k] = fmaf(dx, kx, t);
             }
             const float tb1 = lane_from<-1>(tf[0]), tb2 = lane_from<-2>(tf[1]);

@@ -462,7 +462,17 @@ __global__ __launch_bounds__(TX * ROWS + loader_threads(TX, ROWS)) void k_atrous
     const int r = tid / TX;                 // which of the ROWS rows of an iteration this thread serves
     const int tx = tid - r * TX;
     const int x = x0 + tx;
-    const float kn = gm.kn, kx = gm.kx;
+    // An SGPR or literal source makes a VOP3 occupy the VALU as long as a packed instruction does (tools/ubench6.hip): the two
+    // slopes and the five distinct values of -log2 h of the 24 taps live in VGPRs (profiles/r03_ab_lane_operands.log)
+    float kn = gm.kn, kx = gm.kx;
+    asm volatile("" : "+v"(kn), "+v"(kx));
+    float hc_a = 1.4150374992788437f + 2.0f, hc_b = 4.0f, hc_c = 1.4150374992788437f + 4.0f, hc_d = 6.0f, hc_e = 8.0f;
+    asm volatile("" : "+v"(hc_a), "+v"(hc_b), "+v"(hc_c), "+v"(hc_d), "+v"(hc_e));
+    auto nlh = [&](int io, int j) -> float {      // -log2 h of tap (io, j), never the centre
+        const int ai = io < 0 ? -io : io, aj = j < 0 ? -j : j;
+        const int lo = ai < aj ? ai : aj, hi = ai < aj ? aj : ai;
+        return (lo == 0 && hi == 1) ? hc_a : (lo == 1 && hi == 1) ? hc_b : (lo == 0 && hi == 2) ? hc_c : (lo == 1 && hi == 2) ? hc_d : hc_e;
+    };
     const char *colbase = smem + (size_t)tx * PXB;
 
     int it = 0;
@@ -568,7 +578,7 @@ __global__ __launch_bounds__(TX * ROWS + loader_threads(TX, ROWS)) void k_atrous
 #pragma unroll
                     for (int i = 0; i < 5; i++) {
                         if (i == 2 && j == 0) continue;
-                        float t = fmaf(fabsf(dl[i]), c.kl, neg_log2_binom(i - 2) + neg_log2_binom(j));
+                        float t = fmaf(fabsf(dl[i]), c.kl, nlh(i - 2, j));
                         t = fmaf(dn[i], c.kn, t);
                         e[i] = fmaf(dx[i], c.kx, t);
                     }

@@ -161,12 +161,14 @@ int svgf_synth_camera(int frame, int moving, int width, int height, SvgfCamera *
     float lookat[3] = { 0.0f, 5.0f, 0.0f };
     float theta = PI * 0.5f, phi = 0.0f;
     if (moving) {   // reference src/main.cpp:156-169, speeds of SURVEY.md §8(d) config C3
-        const float k = (float)(frame + 1);
-        lookat[0] = 2.0f * sinf(0.02f * k);
-        lookat[1] = 5.0f + sinf(0.01f * k);
-        lookat[2] = 1.5f * sinf(0.01f * k);
-        theta = PI * 0.5f + PI / 18.0f * sinf(0.01f * k);
-        phi = PI / 12.0f * sinf(0.02f * k);
+        // the phases are accumulated in fp32, one addition per frame, advanced before use (src/main.cpp:158-162)
+        volatile float tx = 0.0f, ty = 0.0f, tz = 0.0f, tt = 0.0f, tp = 0.0f;     // volatile: every sum rounded to fp32
+        for (int k = 0; k <= frame; k++) { tx = tx + 0.02f; ty = ty + 0.01f; tz = tz + 0.01f; tt = tt + 0.01f; tp = tp + 0.02f; }
+        lookat[0] = 2.0f * sinf(tx);
+        lookat[1] = 5.0f + sinf(ty);
+        lookat[2] = 1.5f * sinf(tz);
+        theta = PI * 0.5f + PI / 18.0f * sinf(tt);
+        phi = PI / 12.0f * sinf(tp);
     }
     const float z = 10.5f;
     const float off[3] = { z * sinf(phi) * sinf(theta), z * cosf(theta), z * cosf(phi) * sinf(theta) };

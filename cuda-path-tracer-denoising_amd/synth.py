@@ -33,9 +33,12 @@ def camera_for_frame(frame: int, moving: bool, zoom: float = 10.5, fovy_deg: flo
     theta = F(PI * F(0.5))
     phi = F(0.0)
     if moving:
-        k = F(frame + 1)   # phases are advanced BEFORE use (src/main.cpp:158-162)
-        tx, ty, tz = F(MOVING_SPEEDS["x"]) * k, F(MOVING_SPEEDS["y"]) * k, F(MOVING_SPEEDS["z"]) * k
-        tt, tp = F(MOVING_SPEEDS["theta"]) * k, F(MOVING_SPEEDS["phi"]) * k
+        # the phases are ACCUMULATED in fp32, one addition per frame, and advanced BEFORE use (src/main.cpp:158-162:
+        # `camera_tx += ui_camera_speed_x` ...), not computed as speed * (frame + 1)
+        tx = ty = tz = tt = tp = F(0.0)
+        for _ in range(frame + 1):
+            tx = F(tx + F(MOVING_SPEEDS["x"])); ty = F(ty + F(MOVING_SPEEDS["y"])); tz = F(tz + F(MOVING_SPEEDS["z"]))
+            tt = F(tt + F(MOVING_SPEEDS["theta"])); tp = F(tp + F(MOVING_SPEEDS["phi"]))
         lookat = np.array([F(2.0) * np.sin(tx), F(5.0) + np.sin(ty), F(1.5) * np.sin(tz)], dtype=F)
         theta = F(PI * F(0.5) + PI / F(18) * np.sin(tt))
         phi = F(PI / F(12) * np.sin(tp))
