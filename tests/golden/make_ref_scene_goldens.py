@@ -37,6 +37,7 @@ CASES = [
     ("cornell96_static", "cornell.txt", 96, 96, 4, 0, 0),
     ("cornell128x72_moving", "cornell.txt", 128, 72, 4, 1, 0),
     ("room128x72_static_sepcolor", "room.txt", 128, 72, 4, 0, 1),
+    ("bunny128x72_static", "bunny.txt", 128, 72, 4, 0, 0),          # BASELINE configs[3]'s scene (4 968 triangles)
 ]
 CALL_FMT = "<4i2fi3f5i12fi"
 

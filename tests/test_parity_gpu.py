@@ -218,6 +218,25 @@ def test_4k_size_independent_properties(pkg):
     del torch
 
 
+def test_4k_full_svgf_matches_oracle_static_and_moving(pkg, orc):
+    """BASELINE configs[3] size, 3840x2160, full SVGF (temporal + 5 levels) with the library's default kernel selection —
+    the size where segment lengths, strip counts and the lane / strip choice differ from every golden — against the CPU oracle
+    on EVERY frame of a static and of a moving two-frame sequence: <= 1e-4 relative per channel (north_star's bar)."""
+    W, H = 3840, 2160
+    p = pkg.reference_defaults().set(temporal_enable=1, spatial_enable=1, atrous_nlevel=5, history_level=1)
+    for moving in (False, True):
+        d = pkg.Denoiser(W, H, 0)
+        o = orc.Oracle(pkg, W, H, threads=min(64, __import__("os").cpu_count() or 1))
+        for f in range(2):
+            c, g, cam = pkg.synth.render_frame(W, H, f, seed=41, moving=moving)
+            got = d.denoise_host(c, g, cam, p)
+            ref = o.denoise(c, g, cam, p)
+            e = relerr(got, ref)
+            assert e.max() <= 1e-4, f"4K {'moving' if moving else 'static'} frame {f}: max rel {e.max():.3e}"
+            assert np.array_equal(d.read_state(0), o.read_state(0)), "history length"
+        d.free(); o.free()
+
+
 def test_device_pointers_streams_determinism_and_reset(pkg):
     import torch
     W, H = 384, 216

@@ -21,7 +21,7 @@ CASES = sorted(f[:-4] for f in os.listdir(DIR) if f.endswith(".npz") and not f.e
 
 
 def test_fixtures_present():
-    assert CASES == ["cornell128x72_moving", "cornell96_static", "room128x72_static_sepcolor"]
+    assert CASES == ["bunny128x72_static", "cornell128x72_moving", "cornell96_static", "room128x72_static_sepcolor"]
     z = np.load(os.path.join(DIR, "cornell96_static.npz"))
     g = z["gbuffer"]
     assert g.dtype.itemsize == 52 and set(np.unique(g["geomId"])) >= {-1, 0, 3}      # misses, the light, the mesh
@@ -274,8 +274,7 @@ def test_camera_automation_reproduces_the_reference_cameras(pkg):
     own path tracer used for the moving fixture were captured with the frames (`cams` = right | up | view | position, written
     by oracle/ref/ref_pt_capture.cpp from scene->state.camera): reproduced to fp32 rounding."""
     rec = json.load(open(os.path.join(DIR, "scene_records.json")))["cornell"]["camera"]
-    sc = pkg.scene.Scene()
-    sc.camera = dict(eye=rec["position"], lookat=rec["lookAt"], fovy=rec["fov"][1])
+    sc = pkg.scene.Scene(materials={}, objects=[], camera=dict(eye=rec["position"], lookat=rec["lookAt"], fovy=rec["fov"][1]), skipped=[])
     z = np.load(os.path.join(DIR, "cornell128x72_moving.npz"))
     for f in range(z["cams"].shape[0]):
         cam = pkg.scene.camera_for_frame(sc, f, True)
@@ -284,7 +283,8 @@ def test_camera_automation_reproduces_the_reference_cameras(pkg):
     zs = np.load(os.path.join(DIR, "cornell96_static.npz"))
     cam = pkg.scene.camera_for_frame(sc, 0, False)
     got = np.concatenate([cam["right"], cam["up"], cam["view"], cam["position"]]).astype(np.float32)
-    assert np.abs(got - zs["cams"][0]).max() <= 4e-7
+    # static: the reference rebuilds EYE from (zoom, theta, phi) through acos / sin / cos: one ulp of a coordinate of 5 .. 10.5
+    assert np.abs(got - zs["cams"][0]).max() <= 1e-6
 
 
 @pytest.mark.gpu
@@ -298,8 +298,7 @@ def test_room_1080p_moving_8_frames_device_producer_to_denoiser_vs_oracle(pkg, o
     W, H, N = 1920, 1080, 8
     pi = np.load(os.path.join(DIR, "room_producer_inputs.npz"))
     rec = json.load(open(os.path.join(DIR, "scene_records.json")))["room"]["camera"]
-    sc = pkg.scene.Scene()
-    sc.camera = dict(eye=rec["position"], lookat=rec["lookAt"], fovy=rec["fov"][1])
+    sc = pkg.scene.Scene(materials={}, objects=[], camera=dict(eye=rec["position"], lookat=rec["lookAt"], fovy=rec["fov"][1]), skipped=[])
     p = pkg.reference_defaults().set(temporal_enable=1, spatial_enable=1, atrous_nlevel=5, history_level=1)
     den = pkg.Denoiser(W, H, 0)
     o = orc.Oracle(pkg, W, H, threads=min(64, os.cpu_count() or 1))
