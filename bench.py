@@ -44,10 +44,36 @@ def kernel_sources_sha16():
     return h.hexdigest()[:16]
 
 
+def physical_cores():
+    """(physical cores, CPU model string) of this host, from /proc/cpuinfo; SMT siblings are counted once."""
+    try:
+        seen, model, phys, core = set(), "", None, None
+        for ln in open("/proc/cpuinfo"):
+            k, _, v = ln.partition(":")
+            k, v = k.strip(), v.strip()
+            if k == "model name" and not model:
+                model = v
+            elif k == "physical id":
+                phys = v
+            elif k == "core id":
+                core = v
+            elif not k and phys is not None and core is not None:
+                seen.add((phys, core)); phys = core = None
+        if phys is not None and core is not None:
+            seen.add((phys, core))
+        if seen:
+            return len(seen), model
+    except OSError:
+        pass
+    return os.cpu_count() or 1, ""
+
+
 def cpu_baseline(pkg, frames, params, budget_s=25.0, threads=None, what="full-SVGF", all_cores=True):
-    """CPU oracle (oracle/svgf_oracle.c, OpenMP) on the same workload, bounded sample."""
+    """CPU oracle (oracle/svgf_oracle.c, OpenMP) on the same workload, bounded sample.  Threads are bound one per physical
+    core (OMP_PLACES=cores, OMP_PROC_BIND=close, set in main() before libgomp starts) and rows are dealt in static blocks, so
+    that the all-cores figure is not the SMT + unbound one of round 2 (slower than 64 threads)."""
     orc = ge.load_oracle()
-    cores = os.cpu_count() or 1
+    cores, cpu_model = physical_cores()
     threads = min(cores, 64) if threads is None else threads
     o = orc.Oracle(pkg, W, H, threads=threads)
     t_all, n = 0.0, 0
@@ -64,8 +90,9 @@ def cpu_baseline(pkg, frames, params, budget_s=25.0, threads=None, what="full-SV
     o.free()
     res = {"value": round(W * H / (t_all / n) / 1e6, 3), "unit": "Mpixels/s", "cores": threads, "kind": "port",
            "sample": f"{n} steady-state frames of the same {W}x{H} {what} workload, oracle/svgf_oracle.c "
-                     f"(gcc -O2, OpenMP over rows, {threads} threads of {cores} host cores)"}
-    if all_cores and cores > threads:        # north_star: "the same box's host cores" — every core, next to the 64-thread figure
+                     f"(gcc -O2, OpenMP static row blocks, threads bound to cores; {threads} threads of {cores} physical cores, "
+                     f"{os.cpu_count()} hardware threads, {cpu_model})"}
+    if all_cores and cores > threads:        # north_star: "the same box's host cores" — every physical core, next to the 64-thread figure
         oa = orc.Oracle(pkg, W, H, threads=cores)
         ts = []
         for f in range(3):
@@ -76,7 +103,7 @@ def cpu_baseline(pkg, frames, params, budget_s=25.0, threads=None, what="full-SV
                 ts.append(time.perf_counter() - t0)
         oa.free()
         res["all_cores"] = {"value": round(W * H / (sum(ts) / len(ts)) / 1e6, 3), "unit": "Mpixels/s", "cores": cores,
-                            "sample": f"{len(ts)} steady-state frames, OpenMP over rows on all {cores} host cores"}
+                            "sample": f"{len(ts)} steady-state frames, one bound thread on each of the {cores} physical cores"}
     return res
 
 
@@ -99,10 +126,18 @@ def main():
     ap.add_argument("--host-inputs", action="store_true",
                     help="render the synthetic frames with numpy and upload them (default: the device-side producer, "
                          "svgf_synth_render, SURVEY.md 8f row f1; both give the same frames bit for bit)")
+    ap.add_argument("--planar-inputs", action="store_true",
+                    help="SURVEY.md 8f row f1: the producer writes the G-buffer straight into the denoiser's planes (svgf_planar_gbuffer / "
+                         "svgf_denoise_planar) instead of handing over 52-byte AoS texels; static-camera configs only (the planes of "
+                         "both history parities are filled once, before the timed region, like the AoS inputs)")
     ap.add_argument("--min-warmup-seconds", type=float, default=0.6,
                     help="untimed steps continue after --warmup until this much wall time has passed (clock ramp, history "
                          "fill): a --steps 20 run then measures what a --steps 200 run measures")
     a = ap.parse_args()
+
+    # the CPU-baseline leg: one OpenMP thread per physical core, pinned (read by libgomp when the oracle library is loaded)
+    os.environ.setdefault("OMP_PLACES", "cores")
+    os.environ.setdefault("OMP_PROC_BIND", "close")
 
     import torch
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -130,6 +165,11 @@ def main():
     if world > 1 or os.environ.get("SVGF_BENCH_FORCE_DIST"):   # the env var exercises the RCCL path with one rank
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if "MASTER_PORT" not in os.environ:      # SVGF_BENCH_FORCE_DIST without a launcher: any free port
+            import socket
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     if not torch.cuda.is_available():
@@ -179,9 +219,20 @@ def main():
     den.profile_stride(PROFILE_STRIDE)
     den.profile_enable(a.steps)
 
+    if a.planar_inputs:
+        if moving or a.host_inputs:
+            raise SystemExit("--planar-inputs: static-camera configs with the device producer only")
+        for _ in range(2):      # both plane sets (they alternate with the history) get the static scene's G-buffer
+            pkg.binding.synth_render_planar(d_in[0], den.planar_gbuffer(), W, H, cam_dicts[0], 0, seed=1000 + seq, device=local_rank)
+            den.denoise_planar(out, d_in[0], cams[0], params, stream=stream)
+        torch.cuda.synchronize(dev)
+
     def step(i):
         k = i % nsrc
-        den.denoise(out, d_in[k], d_g[k], cams[k], params, stream=stream)
+        if a.planar_inputs:
+            den.denoise_planar(out, d_in[k], cams[k], params, stream=stream)
+        else:
+            den.denoise(out, d_in[k], d_g[k], cams[k], params, stream=stream)
         return W * H
 
     # warm-up is run with profiling slots too, then the frame counter restarts so slots hold the timed steps only
@@ -250,6 +301,7 @@ def main():
             "config": {"workload": (f"cornell-like {W}x{H}, variance fill + ONE a-trous level (temporal off), " if a.config == "config1" else
                                     f"cornell-like {W}x{H}, full SVGF (temporal + 5 a-trous levels, history_level 1), ")
                                    + ("moving camera, 64-frame sequence replayed" if moving else "static camera, steady-state history")
+                                   + ("; G-buffer handed over as planes written in place by the producer (svgf_denoise_planar)" if a.planar_inputs else "")
                                    + "; one independent sequence per GPU", "name": a.config,
                        "width": W, "height": H, "atrous_levels": 1 if a.config == "config1" else NLEVEL,
                        "parallelism": f"replicas{world}"},

@@ -28,7 +28,8 @@ MAX_LEVELS = 10
 EXPORTS = ["svgf_version", "svgf_params_default", "svgf_create", "svgf_destroy", "svgf_reset", "svgf_denoise",
            "svgf_denoise_host", "svgf_sync", "svgf_last_error", "svgf_width", "svgf_height", "svgf_read_state",
            "svgf_set_capture", "svgf_profile_enable", "svgf_profile_stride", "svgf_profile_frames", "svgf_profile_read",
-           "svgf_synth_camera", "svgf_synth_render", "svgf_scene_render", "svgf_scene_render_mesh", "svgf_display_pack", "svgf_save_png"]
+           "svgf_synth_camera", "svgf_synth_render", "svgf_scene_render", "svgf_scene_render_mesh", "svgf_display_pack", "svgf_save_png",
+           "svgf_planar_gbuffer", "svgf_denoise_planar", "svgf_synth_render_planar", "svgf_params_sizeof"]
 
 
 class SvgfCamera(C.Structure):
@@ -58,6 +59,12 @@ class SvgfParams(C.Structure):
                 raise AttributeError(k)
             setattr(self, k, v)
         return self
+
+
+class SvgfPlanarGBuffer(C.Structure):
+    """Device pointers of the context's current-frame planes (svgf_planar_gbuffer): packed float3 normal / position / albedo,
+    int geomId."""
+    _fields_ = [("normal", C.c_void_p), ("position", C.c_void_p), ("geom_id", C.c_void_p), ("albedo", C.c_void_p)]
 
 
 class SvgfSynthParams(C.Structure):
@@ -125,6 +132,12 @@ def load_library(path: str | None = None):
                                       C.POINTER(C.c_float), vp]
     lib.svgf_scene_render_mesh.argtypes = [ip, vp, vp, ip, ip, C.POINTER(SvgfCamera), C.POINTER(SvgfSynthParams), vp, ip,
                                            vp, vp, vp, vp, ip, vp, vp, vp, ip, C.POINTER(C.c_float), vp]
+    lib.svgf_planar_gbuffer.argtypes = [vp, C.POINTER(SvgfPlanarGBuffer)]
+    lib.svgf_denoise_planar.argtypes = [vp, vp, vp, C.POINTER(SvgfCamera), C.POINTER(SvgfParams), vp]
+    lib.svgf_synth_render_planar.argtypes = [ip, vp, C.POINTER(SvgfPlanarGBuffer), ip, ip, C.POINTER(SvgfCamera), C.POINTER(SvgfSynthParams), vp]
+    lib.svgf_params_sizeof.restype = ip
+    if lib.svgf_params_sizeof() != C.sizeof(SvgfParams):     # the struct grows at its tail between ABI versions
+        raise SvgfError(f"libsvgf_hip.so was built with sizeof(SvgfParams) = {lib.svgf_params_sizeof()}, this binding has {C.sizeof(SvgfParams)}")
     lib.svgf_display_pack.argtypes = [ip, vp, vp, vp, ip, ip, vp]
     lib.svgf_save_png.argtypes = [C.c_char_p, vp, ip, ip, ip]
     if path == LIB_PATH:
@@ -187,6 +200,19 @@ class Denoiser:
         s = None if stream is None else (stream if isinstance(stream, int) else stream.cuda_stream)
         self._check(self.lib.svgf_denoise(self.h, _ptr(out), _ptr(inp), _ptr(gbuffer), C.byref(cam), C.byref(p), s),
                     "svgf_denoise")
+
+    def planar_gbuffer(self) -> SvgfPlanarGBuffer:
+        """The planes the NEXT denoise_planar() call consumes: a producer fills them in place."""
+        g = SvgfPlanarGBuffer()
+        self._check(self.lib.svgf_planar_gbuffer(self.h, C.byref(g)), "svgf_planar_gbuffer")
+        return g
+
+    def denoise_planar(self, out, inp, camera, params: SvgfParams | None = None, stream=None):
+        """One frame whose G-buffer was written into planar_gbuffer()'s planes.  Asynchronous on `stream`."""
+        cam = camera if isinstance(camera, SvgfCamera) else SvgfCamera.from_dict(camera)
+        p = params if params is not None else self.ui
+        s = None if stream is None else (stream if isinstance(stream, int) else stream.cuda_stream)
+        self._check(self.lib.svgf_denoise_planar(self.h, _ptr(out), _ptr(inp), C.byref(cam), C.byref(p), s), "svgf_denoise_planar")
 
     def denoise_host(self, color: np.ndarray, gbuffer: np.ndarray, camera, params: SvgfParams | None = None) -> np.ndarray:
         """numpy in, numpy out (uploads, runs, downloads, synchronises)."""
@@ -268,6 +294,23 @@ def synth_render(out_rgb, out_gbuffer, width: int, height: int, camera, frame: i
         raise SvgfError(f"svgf_synth_render failed ({rc})")
 
 
+def synth_render_planar(out_rgb, planes: SvgfPlanarGBuffer, width: int, height: int, camera, frame: int, seed: int = 1,
+                        noise: float = 0.6, fireflies: float = 0.02, pixel_length=None, device: int = 0, stream=None):
+    """svgf_synth_render_planar: the frame of synth_render written into a Denoiser's planar_gbuffer() planes."""
+    lib = load_library()
+    cam = camera if isinstance(camera, SvgfCamera) else SvgfCamera.from_dict(camera)
+    if pixel_length is None:
+        from . import synth as _synth
+        pixel_length = _synth._pixel_length(width, height, 45.0)
+    sp = SvgfSynthParams(int(frame), int(seed), float(noise), float(fireflies))
+    sp.pixel_length[0] = float(pixel_length[0])
+    sp.pixel_length[1] = float(pixel_length[1])
+    s = None if stream is None else (stream if isinstance(stream, int) else stream.cuda_stream)
+    rc = lib.svgf_synth_render_planar(int(device), _ptr(out_rgb), C.byref(planes), int(width), int(height), C.byref(cam), C.byref(sp), s)
+    if rc != SVGF_OK:
+        raise SvgfError(f"svgf_synth_render_planar failed ({rc})")
+
+
 # --- SURVEY.md 8(f) row f2: the step after denoise() ----------------------------------------------------------------
 def display_pack(pbo, left, right, width: int, height: int, device: int = 0, stream=None):
     """svgf_display_pack: `left` | `right` (packed rgb float, device) -> (height, 2*width, 4) uint8 in device memory."""
@@ -316,8 +359,8 @@ def scene_render_mesh(out_rgb, out_gbuffer, width: int, height: int, camera, geo
                       frame: int, tri_tex=None, textures=None, seed: int = 1, noise: float = 0.6, fireflies: float = 0.02, pixel_length=None, light=None,
                       device: int = 0, stream=None):
     """svgf_scene_render_mesh: primitives (`geoms`, geomId = geom_ids[k]) + world-space triangles (`tris` float32[n,3,8] =
-    pos, normal, uv per corner; geomId = tri_ids[i]; albedo = tri_albedo[i]).  The caller must keep the arrays alive until
-    the stream has run the kernel (the function synchronises when no stream is given)."""
+    pos, normal, uv per corner; geomId = tri_ids[i]; albedo = tri_albedo[i]).  The library has read the host arrays completely
+    when it returns (it waits for its uploads); the kernel itself stays asynchronous on `stream`."""
     from . import scene as _scene
     from . import synth as _synth
     lib = load_library()
@@ -359,4 +402,4 @@ def scene_render_mesh(out_rgb, out_gbuffer, width: int, height: int, camera, geo
         raise SvgfError(f"svgf_scene_render_mesh failed ({rc})")
     if stream is None:
         import torch
-        torch.cuda.synchronize()
+        torch.cuda.synchronize(int(device))

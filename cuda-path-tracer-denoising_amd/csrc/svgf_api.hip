@@ -27,6 +27,7 @@ struct svgf_ctx {
     float *nrm[2];
     int *gid[2];
     float *pos[2];
+    float *albedo;         // planar path only (svgf_planar_gbuffer): packed float3 albedo * ialbedo, allocated on first use
     float2 *mom[2];
     int *hlen[2];
     int hist;      // cv index holding the colour history
@@ -105,6 +106,7 @@ static void view_matrix_from_camera(const SvgfCamera *cam, float *out)
 }
 
 extern "C" int svgf_version(void) { return (SVGF_VERSION_MAJOR << 16) | SVGF_VERSION_MINOR; }
+extern "C" int svgf_params_sizeof(void) { return (int)sizeof(SvgfParams); }
 
 extern "C" int svgf_params_default(SvgfParams *p)
 {
@@ -130,6 +132,7 @@ static void free_all(svgf_ctx *c)
         if (c->hlen[k]) (void)hipFree(c->hlen[k]);
     }
     for (int k = 0; k < 2; k++) if (c->pos[k]) (void)hipFree(c->pos[k]);
+    if (c->albedo) (void)hipFree(c->albedo);
     if (c->side) (void)hipStreamDestroy(c->side);
     if (c->ev_hist) (void)hipEventDestroy(c->ev_hist);
     if (c->ev_temporal) (void)hipEventDestroy(c->ev_temporal);
@@ -212,23 +215,28 @@ extern "C" int svgf_create(int device, int width, int height, svgf_ctx **out)
     return SVGF_OK;
 }
 
-// cross-frame overlap (SvgfParams::inputs_ready): a fourth colour plane, a high-priority side stream and two events
-static int ensure_overlap_resources(svgf_ctx *c)
+// cross-frame overlap (SvgfParams::inputs_ready): a fourth colour plane, a high-priority side stream and two events.
+// Created when a frame first asks for it, possibly on a context that has been running ORDERED frames whose kernels are
+// still queued on the caller's stream `s`: the history event is recorded on that stream right away (and the new planes
+// are cleared on it), so that the first temporal pass on the side stream waits for everything the ordered frames enqueued.
+static int ensure_overlap_resources(svgf_ctx *c, hipStream_t s)
 {
     if (c->side) return SVGF_OK;
     if (!c->cv[3]) {
         HIPC(c, hipMalloc((void **)&c->cv[3], c->n * sizeof(float4)));
-        HIPC(c, hipMemset(c->cv[3], 0, c->n * sizeof(float4)));
+        HIPC(c, hipMemsetAsync(c->cv[3], 0, c->n * sizeof(float4), s));
     }
     if (!c->vp[3]) {
         HIPC(c, hipMalloc((void **)&c->vp[3], (size_t)(c->W + 2) * (c->H + 2) * sizeof(float)));
-        HIPC(c, hipMemset(c->vp[3], 0, (size_t)(c->W + 2) * (c->H + 2) * sizeof(float)));
+        HIPC(c, hipMemsetAsync(c->vp[3], 0, (size_t)(c->W + 2) * (c->H + 2) * sizeof(float), s));
     }
     if (!c->ev_hist) HIPC(c, hipEventCreateWithFlags(&c->ev_hist, hipEventDisableTiming));
     if (!c->ev_temporal) HIPC(c, hipEventCreateWithFlags(&c->ev_temporal, hipEventDisableTiming));
     int lo = 0, hi = 0;   // the side stream carries the short, latency-sensitive temporal pass: highest priority
     (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
     HIPC(c, hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, hi));
+    HIPC(c, hipEventRecord(c->ev_hist, s));
+    c->ev_hist_valid = 1;
     return SVGF_OK;
 }
 
@@ -379,11 +387,12 @@ static bool lane_pays(int W)
     return util_lane * 1.05 >= util_strip;
 }
 
-extern "C" int svgf_denoise(svgf_ctx *c, void *out_rgb_dev, const void *in_rgb_dev, const void *gbuffer_dev,
-                            const SvgfCamera *cam, const SvgfParams *p, void *stream)
+// gbuffer_dev == nullptr: the planar path (svgf_denoise_planar) — the current-frame planes nrm/pos/gid[1 - gcur] (and `albedo`)
+// were filled in place by the producer
+static int denoise_frame(svgf_ctx *c, void *out_rgb_dev, const void *in_rgb_dev, const void *gbuffer_dev,
+                         const SvgfCamera *cam, const SvgfParams *p, void *stream)
 {
-    if (!c) return SVGF_ERR_INVALID_ARG;
-    if (!out_rgb_dev || !in_rgb_dev || !gbuffer_dev || !cam || !p) {
+    if (!out_rgb_dev || !in_rgb_dev || !cam || !p) {
         snprintf(c->err, sizeof(c->err), "svgf_denoise: null argument");
         return SVGF_ERR_INVALID_ARG;
     }
@@ -435,7 +444,7 @@ extern "C" int svgf_denoise(svgf_ctx *c, void *out_rgb_dev, const void *in_rgb_d
     //    Only the temporal pass is worth a second stream: the constant-variance fill of the non-temporal mode is a
     //    few microseconds, less than the cross-stream event hand-off costs.
     const bool overlap = (p->inputs_ready != 0) && (p->temporal_enable != 0);
-    if (overlap) { const int rc = ensure_overlap_resources(c); if (rc != SVGF_OK) return rc; }
+    if (overlap) { const int rc = ensure_overlap_resources(c, (hipStream_t)stream); if (rc != SVGF_OK) return rc; }
     const int ncv = c->cv[3] ? 4 : 3;
     // planes the previous frame's trailing levels still write matter only when this frame's temporal pass may run beside
     // them (side stream); on the ordered path the stream order protects them
@@ -467,9 +476,9 @@ extern "C" int svgf_denoise(svgf_ctx *c, void *out_rgb_dev, const void *in_rgb_d
             t.reproj_sx = p->reproj_scale[0]; t.reproj_sy = p->reproj_scale[1];
             t.pos_prev = c->pos[c->gcur]; t.pos_tol = p->reproj_position_tol;
             LAUNCH_T(SVGF_KERNEL_TEMPORAL, launch_temporal(t, ts, overlap && c->ev_hist_valid));
-            if (p->spatial_variance_frames > 0)      // f4 extension: spatial variance estimate for short histories
-                HIPC(c, launch_spatial_variance(c->cv[acc], c->mom[1 - c->cur], c->hlen[1 - c->cur], c->nrm[gnew], c->gid[gnew],
-                                                c->W, c->H, p->spatial_variance_frames, ts));
+            if (p->spatial_variance_frames > 0)      // f4 extension: spatial variance estimate for short histories (its own profiling slot, same kind)
+                LAUNCH_T(SVGF_KERNEL_TEMPORAL, launch_spatial_variance(c->cv[acc], c->mom[1 - c->cur], c->hlen[1 - c->cur], c->nrm[gnew], c->gid[gnew],
+                                                                       c->W, c->H, p->spatial_variance_frames, ts));
         } else {
             LAUNCH_T(SVGF_KERNEL_PREPARE, launch_prepare(in, g, c->cv[acc], c->nrm[gnew], c->gid[gnew], c->pos[gnew], c->W, c->H, ts));
         }
@@ -519,7 +528,7 @@ extern "C" int svgf_denoise(svgf_ctx *c, void *out_rgb_dev, const void *in_rgb_d
             }
             AtrousArgs a;
             a.src = c->cv[src]; a.dst = dst >= 0 ? c->cv[dst] : nullptr; a.out_rgb = last ? out : nullptr;
-            a.nrm = c->nrm[gnew]; a.pos = c->pos[gnew]; a.gbuf = g;
+            a.nrm = c->nrm[gnew]; a.pos = c->pos[gnew]; a.gbuf = g; a.albedo = c->albedo;
             a.W = c->W; a.H = c->H;
             a.step = 1 << (p->paper_steps ? level - 1 : level);   // reference: level starts at 1 => steps 2,4,8,16,32 (:98,386)
             a.sigma_c = p->sigma_l; a.sigma_n = p->sigma_n; a.sigma_x = p->sigma_x;
@@ -574,6 +583,42 @@ extern "C" int svgf_denoise(svgf_ctx *c, void *out_rgb_dev, const void *in_rgb_d
     if (timer.on) c->prof_count++;
     c->frame_no++;
     return SVGF_OK;
+}
+
+extern "C" int svgf_denoise(svgf_ctx *c, void *out_rgb_dev, const void *in_rgb_dev, const void *gbuffer_dev,
+                            const SvgfCamera *cam, const SvgfParams *p, void *stream)
+{
+    if (!c) return SVGF_ERR_INVALID_ARG;
+    if (!gbuffer_dev) {
+        snprintf(c->err, sizeof(c->err), "svgf_denoise: null argument");
+        return SVGF_ERR_INVALID_ARG;
+    }
+    return denoise_frame(c, out_rgb_dev, in_rgb_dev, gbuffer_dev, cam, p, stream);
+}
+
+// ---- the planar path (the AoS -> plane repack fused into the producer) -----------------------
+extern "C" int svgf_planar_gbuffer(svgf_ctx *c, SvgfPlanarGBuffer *out)
+{
+    if (!c || !out) return SVGF_ERR_INVALID_ARG;
+    SvgfDeviceGuard dev_guard(c->device);
+    if (!dev_guard.ok) { snprintf(c->err, sizeof(c->err), "hipSetDevice(%d) failed", c->device); return SVGF_ERR_HIP; }
+    if (!c->albedo) {
+        HIPC(c, hipMalloc((void **)&c->albedo, c->n * 3 * sizeof(float)));
+        HIPC(c, hipMemset(c->albedo, 0, c->n * 3 * sizeof(float)));
+    }
+    const int gnew = 1 - c->gcur;        // the planes the next frame's temporal / prepare pass treats as "current"
+    out->normal = c->nrm[gnew]; out->position = c->pos[gnew]; out->geom_id = c->gid[gnew]; out->albedo = c->albedo;
+    return SVGF_OK;
+}
+
+extern "C" int svgf_denoise_planar(svgf_ctx *c, void *out_rgb_dev, const void *in_rgb_dev, const SvgfCamera *cam, const SvgfParams *p, void *stream)
+{
+    if (!c) return SVGF_ERR_INVALID_ARG;
+    if (p && p->sepcolor && p->addcolor && !c->albedo) {
+        snprintf(c->err, sizeof(c->err), "svgf_denoise_planar: sepcolor && addcolor needs the albedo plane of svgf_planar_gbuffer");
+        return SVGF_ERR_INVALID_ARG;
+    }
+    return denoise_frame(c, out_rgb_dev, in_rgb_dev, nullptr, cam, p, stream);
 }
 
 extern "C" int svgf_denoise_host(svgf_ctx *c, float *out_rgb_host, const float *in_rgb_host,

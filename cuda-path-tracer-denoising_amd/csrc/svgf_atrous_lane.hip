@@ -734,10 +734,7 @@ __global__ __launch_bounds__(NT) void k_atrous_lane(AtrousArgs a, LaneGeom gm)
                 o0 = C.x; o1 = C.y; o2 = C.z; ov = C.w;
             }
             const unsigned p = (unsigned)y * (unsigned)W + (unsigned)x;
-            if (a.modulate) {                                      // last level: * albedo * ialbedo (:166-168)
-                const float *t = a.gbuf + 13u * (size_t)p;
-                o0 *= t[6] * t[9]; o1 *= t[7] * t[10]; o2 *= t[8] * t[11];
-            }
+            if (a.modulate) svgf_modulate(a, p, o0, o1, o2);       // last level: * albedo * ialbedo (:166-168)
             if (a.dst) a.dst[p] = make_float4(o0, o1, o2, ov);
             if (a.var_dst) a.var_dst[(unsigned)(y + 1) * (unsigned)(W + 2) + (unsigned)(x + 1)] = ov;
             if (a.out_rgb) { float *o = a.out_rgb + 3u * p; o[0] = o0; o[1] = o1; o[2] = o2; }

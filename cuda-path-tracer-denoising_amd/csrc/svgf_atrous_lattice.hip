@@ -215,10 +215,7 @@ __global__ __launch_bounds__(NT) void k_atrous_lattice(AtrousArgs a, LatticeGeom
         } else {
             o0 = C.x; o1 = C.y; o2 = C.z; ov = C.w;
         }
-        if (a.modulate) {                                          // last level: * albedo * ialbedo (:166-168)
-            const float *t = a.gbuf + 13u * (size_t)p;
-            o0 *= t[6] * t[9]; o1 *= t[7] * t[10]; o2 *= t[8] * t[11];
-        }
+        if (a.modulate) svgf_modulate(a, (unsigned)p, o0, o1, o2);  // last level: * albedo * ialbedo (:166-168)
         if (a.dst) a.dst[p] = make_float4(o0, o1, o2, ov);
         if (a.out_rgb) { float *q = a.out_rgb + 3u * (size_t)p; q[0] = o0; q[1] = o1; q[2] = o2; }
     }

@@ -59,7 +59,8 @@ struct AtrousArgs {
     float *out_rgb;           // packed rgb output (user buffer), null except on the last level
     const float *nrm;         // packed float3
     const float *pos;         // packed float3
-    const float *gbuf;        // raw 52-B texels, only read when modulate != 0 (albedo*ialbedo, reference :166-168)
+    const float *gbuf;        // raw 52-B texels, only read when modulate != 0 (albedo*ialbedo, reference :166-168); null on the planar path
+    const float *albedo;      // planar path (svgf_denoise_planar): packed float3 albedo*ialbedo per pixel, read instead of gbuf
     int W, H, step;
     float sigma_c, sigma_n, sigma_x;
     int blur_variance;
@@ -70,7 +71,8 @@ struct AtrousArgs {
 
 struct TemporalArgs {
     const float *in_rgb;      // packed rgb, current 1-spp colour
-    const float *gbuf;        // raw 52-B texels
+    const float *gbuf;        // raw 52-B texels; null on the planar path: nrm_cur / pos_cur / gid_cur then hold this frame's
+                              // G-buffer already (written by the producer) and are read instead of being written
     const float4 *cv_hist;    // colour history (rgb used)
     float4 *cv_acc;           // out: {colour_acc, variance}
     const float2 *mom_hist; float2 *mom_acc;
@@ -90,6 +92,7 @@ hipError_t launch_temporal(const TemporalArgs &a, hipStream_t s, bool single_wav
 hipError_t launch_spatial_variance(float4 *cv_acc, const float2 *mom_acc, const int *hlen_upd, const float *nrm, const int *gid,
                                    int W, int H, int K, hipStream_t s);
 // non-temporal mode: variance = 10, colour = input, split G-buffer (reference EstimateVariance :320-329 + :370)
+// (gbuf null: the planar path, the planes are already filled and only the colour plane is written)
 hipError_t launch_prepare(const float *in_rgb, const float *gbuf, float4 *cv, float *nrm, int *gid, float *pos,
                           int W, int H, hipStream_t s);
 hipError_t launch_atrous_gather(const AtrousArgs &a, hipStream_t s);   // strict one-thread-per-pixel gather kernel
@@ -99,6 +102,18 @@ hipError_t launch_atrous_lane(const AtrousArgs &a, hipStream_t s);     // lane-m
 bool       atrous_lane_supported(const AtrousArgs &a);
 hipError_t launch_atrous_lattice(const AtrousArgs &a, hipStream_t s);  // lattice sub-images in LDS (steps >= 64)
 bool       atrous_lattice_supported(const AtrousArgs &a);
+// albedo * ialbedo of the last level's re-modulation (:166-168), from the AoS texel or from the planar path's plane
+__device__ __forceinline__ void svgf_modulate(const AtrousArgs &a, unsigned p, float &o0, float &o1, float &o2)
+{
+    if (a.gbuf) {
+        const float *t = a.gbuf + 13u * (size_t)p;
+        o0 *= t[6] * t[9]; o1 *= t[7] * t[10]; o2 *= t[8] * t[11];
+    } else {
+        const float *t = a.albedo + 3u * (size_t)p;
+        o0 *= t[0]; o1 *= t[1]; o2 *= t[2];
+    }
+}
+
 // out = float(value)/scale broadcast to rgb (reference DebugView :331-340)
 hipError_t launch_debug_hlen(const int *hlen, float *out_rgb, int n, float scale, hipStream_t s);
 hipError_t launch_debug_var(const float4 *cv, float *out_rgb, int n, float scale, hipStream_t s);

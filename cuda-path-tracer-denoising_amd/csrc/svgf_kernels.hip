@@ -68,13 +68,21 @@ __global__ __launch_bounds__(BLOCK) void k_temporal(TemporalArgs a)
     const int p = blockIdx.x * BLOCK + threadIdx.x;
     if (p >= n) return;
 
-    const float *t = a.gbuf + 13 * (size_t)p;
-    const float nx = t[0], ny = t[1], nz = t[2];
-    const float px = t[3], py = t[4], pz = t[5];
-    const int gid = __float_as_int(t[12]);
-    a.nrm_cur[3 * (size_t)p] = nx; a.nrm_cur[3 * (size_t)p + 1] = ny; a.nrm_cur[3 * (size_t)p + 2] = nz;
-    a.pos_cur[3 * (size_t)p] = px; a.pos_cur[3 * (size_t)p + 1] = py; a.pos_cur[3 * (size_t)p + 2] = pz;
-    a.gid_cur[p] = gid;
+    float nx, ny, nz, px, py, pz;
+    int gid;
+    if (a.gbuf) {             // the boundary's AoS texel (52 B): read once, split into the planes every later kernel reads
+        const float *t = a.gbuf + 13 * (size_t)p;
+        nx = t[0]; ny = t[1]; nz = t[2];
+        px = t[3]; py = t[4]; pz = t[5];
+        gid = __float_as_int(t[12]);
+        a.nrm_cur[3 * (size_t)p] = nx; a.nrm_cur[3 * (size_t)p + 1] = ny; a.nrm_cur[3 * (size_t)p + 2] = nz;
+        a.pos_cur[3 * (size_t)p] = px; a.pos_cur[3 * (size_t)p + 1] = py; a.pos_cur[3 * (size_t)p + 2] = pz;
+        a.gid_cur[p] = gid;
+    } else {                  // planar path: the producer wrote the planes in place (svgf_planar_gbuffer), 28 B read, nothing split
+        nx = a.nrm_cur[3 * (size_t)p]; ny = a.nrm_cur[3 * (size_t)p + 1]; nz = a.nrm_cur[3 * (size_t)p + 2];
+        px = a.pos_cur[3 * (size_t)p]; py = a.pos_cur[3 * (size_t)p + 1]; pz = a.pos_cur[3 * (size_t)p + 2];
+        gid = a.gid_cur[p];
+    }
 
     const float cr = a.in_rgb[3 * (size_t)p], cg = a.in_rgb[3 * (size_t)p + 1], cb = a.in_rgb[3 * (size_t)p + 2];
     const float lum = lum_strict(cr, cg, cb);
@@ -229,10 +237,12 @@ __global__ __launch_bounds__(SVGF_BLOCK) void k_prepare(const float *__restrict_
 {
     const int p = blockIdx.x * SVGF_BLOCK + threadIdx.x;
     if (p >= n) return;
-    const float *t = gbuf + 13 * (size_t)p;
-    nrm[3 * (size_t)p] = t[0]; nrm[3 * (size_t)p + 1] = t[1]; nrm[3 * (size_t)p + 2] = t[2];
-    pos[3 * (size_t)p] = t[3]; pos[3 * (size_t)p + 1] = t[4]; pos[3 * (size_t)p + 2] = t[5];
-    gid[p] = __float_as_int(t[12]);
+    if (gbuf) {               // null on the planar path: the producer filled the planes itself
+        const float *t = gbuf + 13 * (size_t)p;
+        nrm[3 * (size_t)p] = t[0]; nrm[3 * (size_t)p + 1] = t[1]; nrm[3 * (size_t)p + 2] = t[2];
+        pos[3 * (size_t)p] = t[3]; pos[3 * (size_t)p + 1] = t[4]; pos[3 * (size_t)p + 2] = t[5];
+        gid[p] = __float_as_int(t[12]);
+    }
     cv[p] = make_float4(in_rgb[3 * (size_t)p], in_rgb[3 * (size_t)p + 1], in_rgb[3 * (size_t)p + 2], 10.0f);
 }
 
@@ -314,10 +324,7 @@ __global__ __launch_bounds__(SVGF_BLOCK) void k_atrous_gather(AtrousArgs a)
     } else {
         o0 = cp.x; o1 = cp.y; o2 = cp.z; ov = cp.w;
     }
-    if (a.modulate) {                                                 // last level: * albedo * ialbedo (:166-168)
-        const float *t = a.gbuf + 13 * (size_t)p;
-        o0 *= t[6] * t[9]; o1 *= t[7] * t[10]; o2 *= t[8] * t[11];
-    }
+    if (a.modulate) svgf_modulate(a, (unsigned)p, o0, o1, o2);        // last level: * albedo * ialbedo (:166-168)
     if (a.dst) a.dst[p] = make_float4(o0, o1, o2, ov);
     if (a.out_rgb) { a.out_rgb[3 * (size_t)p] = o0; a.out_rgb[3 * (size_t)p + 1] = o1; a.out_rgb[3 * (size_t)p + 2] = o2; }
 }

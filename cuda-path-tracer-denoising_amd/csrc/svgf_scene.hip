@@ -213,12 +213,15 @@ extern "C" int svgf_scene_render_mesh(int device, void *out_rgb_dev, void *out_g
     if (n_geoms < 0 || n_geoms > SVGF_SCENE_MAX_GEOMS || (n_geoms > 0 && !geoms)) return SVGF_ERR_INVALID_ARG;
     if (n_tris < 0 || n_tris > SVGF_SCENE_MAX_TRIS || (n_tris > 0 && (!tris || !tri_ids || !tri_albedo))) return SVGF_ERR_INVALID_ARG;
     if (n_tex < 0 || n_tex > 64 || (n_tex > 0 && (!tri_tex || !tex_desc || !tex_data || n_tris == 0))) return SVGF_ERR_INVALID_ARG;
-    size_t b_tex = 16;
+    size_t n_texbytes = 0;              // bytes of tex_data the descriptors reach: that much is copied, not a byte more
     for (int k = 0; k < n_tex; k++) {
         if (tex_desc[3 * k] < 0 || tex_desc[3 * k + 1] <= 0 || tex_desc[3 * k + 2] <= 0) return SVGF_ERR_INVALID_ARG;
         const size_t end = (size_t)tex_desc[3 * k] + (size_t)3 * tex_desc[3 * k + 1] * tex_desc[3 * k + 2];
-        if (end > b_tex) b_tex = end;
+        if (end > n_texbytes) n_texbytes = end;
     }
+    for (int i = 0; i < n_tris && n_tex > 0; i++)      // -1 = untextured; anything else must name one of the n_tex textures
+        if (tri_tex[i] < -1 || tri_tex[i] >= n_tex) return SVGF_ERR_INVALID_ARG;
+    const size_t b_tex = n_texbytes > 16 ? n_texbytes : 16;     // the allocation is padded, the copy is not
     if ((long long)width * height >= (1LL << 31) / 16) return SVGF_ERR_UNSUPPORTED;
     SvgfDeviceGuard dev_guard(device);
     if (!dev_guard.ok) return SVGF_ERR_NO_DEVICE;
@@ -242,8 +245,11 @@ extern "C" int svgf_scene_render_mesh(int device, void *out_rgb_dev, void *out_g
     if (n_tex > 0) {
         ok = ok && hipMemcpyAsync(d + o_tt, tri_tex, sizeof(int) * (size_t)n_tris, hipMemcpyHostToDevice, s) == hipSuccess;
         ok = ok && hipMemcpyAsync(d + o_td, tex_desc, sizeof(int) * 3 * (size_t)n_tex, hipMemcpyHostToDevice, s) == hipSuccess;
-        ok = ok && hipMemcpyAsync(d + o_tex, tex_data, b_tex, hipMemcpyHostToDevice, s) == hipSuccess;
+        ok = ok && hipMemcpyAsync(d + o_tex, tex_data, n_texbytes, hipMemcpyHostToDevice, s) == hipSuccess;
     }
+    // the host arrays are the caller's (usually pageable, often temporaries of a binding): they have been read completely
+    // when this function returns — the uploads are waited for here, the kernel behind them stays asynchronous
+    ok = ok && hipStreamSynchronize(s) == hipSuccess;
     if (!ok) { (void)hipFreeAsync(d, s); return SVGF_ERR_HIP; }
     SceneArgs a;
     for (int c = 0; c < 3; c++) { a.right[c] = cam->right[c]; a.up[c] = cam->up[c]; a.view[c] = cam->view[c]; a.o[c] = cam->position[c]; a.light[c] = light[c]; }

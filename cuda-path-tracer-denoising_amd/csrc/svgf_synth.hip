@@ -26,7 +26,8 @@ struct SynthArgs {
     float noise, fireflies, chroma_amp;
     int W, H, frame, seed;
     float *out_rgb;
-    float *out_gbuf;
+    float *out_gbuf;           // AoS texels, or null: the planes below
+    float *pl_nrm, *pl_pos, *pl_alb; int *pl_gid;
 };
 
 // scene of synth.py: room x in [-5,5], y in [0,10], z in [-5,5] (open towards +z), two spheres, one box, one light
@@ -142,6 +143,13 @@ __global__ __launch_bounds__(256) void k_synth_frame(SynthArgs a)
 
     float *o_rgb = a.out_rgb + 3 * (size_t)p;
     o_rgb[0] = col[0]; o_rgb[1] = col[1]; o_rgb[2] = col[2];
+    if (!a.out_gbuf) {        // planar: the denoiser's own current-frame planes (svgf_planar_gbuffer); albedo * ialbedo, ialbedo == 1
+        a.pl_nrm[3 * (size_t)p] = n[0]; a.pl_nrm[3 * (size_t)p + 1] = n[1]; a.pl_nrm[3 * (size_t)p + 2] = n[2];
+        a.pl_pos[3 * (size_t)p] = pos[0]; a.pl_pos[3 * (size_t)p + 1] = pos[1]; a.pl_pos[3 * (size_t)p + 2] = pos[2];
+        if (a.pl_alb) { a.pl_alb[3 * (size_t)p] = alb[0]; a.pl_alb[3 * (size_t)p + 1] = alb[1]; a.pl_alb[3 * (size_t)p + 2] = alb[2]; }
+        a.pl_gid[p] = gid;
+        return;
+    }
     float *g = a.out_gbuf + 13 * (size_t)p;                          // SvgfGBufferTexel, 52 B
     g[0] = n[0]; g[1] = n[1]; g[2] = n[2];
     g[3] = pos[0]; g[4] = pos[1]; g[5] = pos[2];
@@ -189,10 +197,11 @@ int svgf_synth_camera(int frame, int moving, int width, int height, SvgfCamera *
     return SVGF_OK;
 }
 
-int svgf_synth_render(int device, void *out_rgb_dev, void *out_gbuffer_dev, int width, int height,
-                      const SvgfCamera *cam, const SvgfSynthParams *sp, void *stream)
+static int synth_render_impl(int device, void *out_rgb_dev, void *out_gbuffer_dev, const SvgfPlanarGBuffer *planes, int width, int height,
+                             const SvgfCamera *cam, const SvgfSynthParams *sp, void *stream)
 {
-    if (!out_rgb_dev || !out_gbuffer_dev || !cam || !sp || width <= 0 || height <= 0) return SVGF_ERR_INVALID_ARG;
+    if (!out_rgb_dev || (!out_gbuffer_dev && !planes) || !cam || !sp || width <= 0 || height <= 0) return SVGF_ERR_INVALID_ARG;
+    if (planes && (!planes->normal || !planes->position || !planes->geom_id)) return SVGF_ERR_INVALID_ARG;
     if ((long long)width * height >= (1LL << 31) / 16) return SVGF_ERR_UNSUPPORTED;
     SvgfDeviceGuard dev_guard(device);
     if (!dev_guard.ok) return SVGF_ERR_NO_DEVICE;
@@ -204,9 +213,27 @@ int svgf_synth_render(int device, void *out_rgb_dev, void *out_gbuffer_dev, int 
     a.W = width; a.H = height; a.frame = sp->frame; a.seed = sp->seed;
     a.out_rgb = static_cast<float *>(out_rgb_dev);
     a.out_gbuf = static_cast<float *>(out_gbuffer_dev);
+    a.pl_nrm = planes ? planes->normal : nullptr; a.pl_pos = planes ? planes->position : nullptr;
+    a.pl_alb = planes ? planes->albedo : nullptr; a.pl_gid = planes ? planes->geom_id : nullptr;
     const int n = width * height;
     hipLaunchKernelGGL(k_synth_frame, dim3((n + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), a);
     return hipGetLastError() == hipSuccess ? SVGF_OK : SVGF_ERR_HIP;
+}
+
+int svgf_synth_render(int device, void *out_rgb_dev, void *out_gbuffer_dev, int width, int height,
+                      const SvgfCamera *cam, const SvgfSynthParams *sp, void *stream)
+{
+    if (!out_gbuffer_dev) return SVGF_ERR_INVALID_ARG;
+    return synth_render_impl(device, out_rgb_dev, out_gbuffer_dev, nullptr, width, height, cam, sp, stream);
+}
+
+// SURVEY.md 8f row f1, second half: the repack fused into the producer (src/pathtrace.cu:317-323 is where the reference fills
+// its AoS texel): the same pixels written straight into the denoiser's planes
+int svgf_synth_render_planar(int device, void *out_rgb_dev, const SvgfPlanarGBuffer *out_planes, int width, int height,
+                             const SvgfCamera *cam, const SvgfSynthParams *sp, void *stream)
+{
+    if (!out_planes) return SVGF_ERR_INVALID_ARG;
+    return synth_render_impl(device, out_rgb_dev, nullptr, out_planes, width, height, cam, sp, stream);
 }
 
 }  // extern "C"

@@ -204,13 +204,40 @@ int svgf_synth_camera(int frame, int moving, int width, int height, SvgfCamera *
 int svgf_synth_render(int device, void *out_rgb_dev, void *out_gbuffer_dev, int width, int height,
                       const SvgfCamera *cam, const SvgfSynthParams *sp, void *stream);
 
+/* ---- "next" row f1, second half: the AoS -> plane repack fused into the producer ---------
+ * svgf_denoise reads the reference's 52-byte AoS texel (src/sceneStructs.h:113-119) once per frame and splits it into the
+ * planes every later kernel works on (packed float3 normals, packed float3 positions, int geomId): 52 B/px fetched, 28 B/px
+ * written, only because the producer and the consumer do not share a layout.  A producer that can write planes gets the
+ * context's OWN current-frame planes from svgf_planar_gbuffer and fills them in place (src/pathtrace.cu:317-323 is where
+ * the reference fills its texel); svgf_denoise_planar then runs the frame without touching an AoS G-buffer at all.
+ *   normal, position: packed float3 per pixel; geom_id: int per pixel (-1 = miss); albedo: packed float3 per pixel holding
+ *   albedo * ialbedo (only read on the last level when sepcolor && addcolor; may be left unwritten otherwise).
+ * The pointers are valid for exactly ONE svgf_denoise_planar call on this context (the planes rotate with the history: ask
+ * again for the next frame); producer and svgf_denoise_planar must be ordered on the same stream.  Results are bit-identical
+ * to svgf_denoise on the same texels (tests/test_planar_inputs.py).  AoS and planar frames may alternate on one context. */
+typedef struct SvgfPlanarGBuffer {
+    float *normal;
+    float *position;
+    int   *geom_id;
+    float *albedo;
+} SvgfPlanarGBuffer;
+int svgf_planar_gbuffer(svgf_ctx *ctx, SvgfPlanarGBuffer *out);
+int svgf_denoise_planar(svgf_ctx *ctx, void *out_rgb_dev, const void *in_rgb_dev, const SvgfCamera *cam, const SvgfParams *p, void *stream);
+/* svgf_synth_render writing those planes instead of the AoS texel (same pixels, same values) */
+int svgf_synth_render_planar(int device, void *out_rgb_dev, const SvgfPlanarGBuffer *out_planes, int width, int height,
+                             const SvgfCamera *cam, const SvgfSynthParams *sp, void *stream);
+/* sizeof(SvgfParams) of THIS build of the library: the struct has grown at its tail (ABI 0.2: 72 bytes, 0.3: 80) and
+ * svgf_denoise reads all of it, so a binding compiled against an older header must not be mixed with a newer library:
+ * compare this with the size of your own struct at load time (the Python binding and denoise_compat.cpp do). */
+int svgf_params_sizeof(void);
+
 /* ---- "next" row f3: scene-driven producer --------------------------------------------------------
- * The reference's scenes are transformed unit cubes / spheres (src/scene.cpp:47-117, src/intersections.h:50,104; meshes
- * belong to the out-of-scope path tracer).  The host side (scene.py: the MATERIAL / OBJECT / CAMERA text format) builds
- * these records; svgf_scene_render casts the primary rays against them and writes colour + G-buffer like
- * svgf_synth_render does for its built-in scene.  geomId = index into `geoms`.  `geoms` and `light` are host memory;
- * `geoms` is uploaded with an asynchronous copy on `stream` and must stay valid and unchanged until the stream has
- * consumed it (synchronise the stream before freeing or rewriting it). */
+ * The reference's scenes are transformed unit cubes / spheres (src/scene.cpp:47-117, src/intersections.h:50,104) and OBJ
+ * triangle meshes (svgf_scene_render_mesh below).  The host side (scene.py: the MATERIAL / OBJECT / CAMERA text format)
+ * builds these records; svgf_scene_render casts the primary rays against them and writes colour + G-buffer like
+ * svgf_synth_render does for its built-in scene.  geomId = index into `geoms`.  `geoms` and `light` are host memory:
+ * the library has read them completely when the call returns (it waits for its own uploads; the kernel behind them stays
+ * asynchronous on `stream`). */
 #define SVGF_SCENE_MAX_GEOMS 64
 typedef struct SvgfSceneGeom {
     int   type;              /* 0 cube [-0.5,0.5]^3, 1 sphere r = 0.5 (object space) */
@@ -224,11 +251,13 @@ typedef struct SvgfSceneGeom {
 int svgf_scene_render(int device, void *out_rgb_dev, void *out_gbuffer_dev, int width, int height,
                       const SvgfCamera *cam, const SvgfSynthParams *sp, const SvgfSceneGeom *geoms, int n_geoms,
                       const float light[3], void *stream);
-/* The same with the scene's triangle meshes (Scene::loadMesh's world-space triangles, src/scene.cpp:234-311; host arrays, same
- * lifetime rule as `geoms`): `tris` = n_tris x 3 vertices x {pos[3], normal[3], uv[2]}, `tri_ids` = the object index written as
+/* The same with the scene's triangle meshes (Scene::loadMesh's world-space triangles, src/scene.cpp:234-311; host arrays, read
+ * completely before the call returns like `geoms`; every triangle is tested for every pixel — no BVH, the reference's
+ * scenes have 38 .. 4 968 triangles — so n_tris x width x height is what a call costs): `tris` = n_tris x 3 vertices x {pos[3], normal[3], uv[2]}, `tri_ids` = the object index written as
  * geomId for each triangle, `tri_albedo` = n_tris x rgb (the mesh's material colour), `geom_ids` = the object index written
  * as geomId for each primitive (NULL: its position in `geoms`).  Textures (n_tex may be 0): `tex_data` = 8-bit RGB images, rows
- * top to bottom, `tex_desc` = n_tex x {byte offset into tex_data, width, height}, `tri_tex` = texture index per triangle or -1;
+ * top to bottom, `tex_desc` = n_tex x {byte offset into tex_data, width, height}, `tri_tex` = texture index per triangle or -1
+ * (anything outside [-1, n_tex) is SVGF_ERR_INVALID_ARG);
  * a textured triangle's albedo is Texture::getColor at the interpolated uv (src/sceneStructs.h:208-219, :162-164).  First hit as the
  * reference's computeIntersection (src/pathtrace.cu:211-276): nearest of primitives and the nearest triangle of the scene
  * (glm::intersectRayTriangle), mesh normal interpolated with Triangle::Intersect's corner weights (src/sceneStructs.h:168-172). */

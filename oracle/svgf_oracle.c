@@ -175,7 +175,7 @@ void svgf_oracle_atrous(const float *colorin, float *colorout, const float *vari
     }
     (void)nthreads;
 #ifdef _OPENMP
-#pragma omp parallel for schedule(dynamic, 4) num_threads(nthreads > 0 ? nthreads : 1)
+#pragma omp parallel for schedule(static) num_threads(nthreads > 0 ? nthreads : 1)
 #endif
     for (int y = 0; y < H; y++)
         for (int x = 0; x < W; x++)
@@ -311,7 +311,7 @@ void svgf_oracle_backproject_ex(float *variance_out, const int *history_length, 
 {
     (void)nthreads;
 #ifdef _OPENMP
-#pragma omp parallel for schedule(dynamic, 4) num_threads(nthreads > 0 ? nthreads : 1)
+#pragma omp parallel for schedule(static) num_threads(nthreads > 0 ? nthreads : 1)
 #endif
     for (int y = 0; y < H; y++)
         for (int x = 0; x < W; x++)
@@ -330,7 +330,7 @@ void svgf_oracle_spatial_variance(float *variance, const float *moment_acc, cons
 {
     (void)nthreads;
 #ifdef _OPENMP
-#pragma omp parallel for schedule(dynamic, 4) num_threads(nthreads > 0 ? nthreads : 1)
+#pragma omp parallel for schedule(static) num_threads(nthreads > 0 ? nthreads : 1)
 #endif
     for (int y = 0; y < H; y++)
         for (int x = 0; x < W; x++) {

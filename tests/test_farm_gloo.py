@@ -82,3 +82,27 @@ def test_bench_refuses_to_run_without_a_gpu():
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
     assert r.returncode != 0
     assert "needs a GPU" in (r.stderr + r.stdout)
+
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.gpu
+def test_bench_distributed_branch_runs_with_one_rank_on_rccl():
+    """The multi-GPU branch of bench.py (RCCL process group on `nccl`, barrier + MAX / SUM all-reduces around the timed region)
+    as far as a one-GPU box can exercise it: SVGF_BENCH_FORCE_DIST=1 takes that branch with world size 1.  The JSON line must
+    carry BASELINE's metric and the same fields as the plain run."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = dict(os.environ, SVGF_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1")
+    env.pop("MASTER_PORT", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "5", "--warmup", "2", "--no-cpu-baseline",
+                        "--min-warmup-seconds", "0.1"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["metric"].startswith("SVGF Mpixels/s (full pipeline) at 1080p") and line["unit"] == "Mpixels/s"
+    assert line["n_gpus"] == 1 and line["steps"] == 5 and line["scaling"] == "weak" and line["value"] > 100
+    assert 0 < line["roofline"]["frac"] < 1 and line["config"]["parallelism"] == "replicas1"

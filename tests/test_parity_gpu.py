@@ -323,6 +323,34 @@ def test_cross_frame_overlap_is_bit_identical(pkg, history_level):
         assert np.array_equal(a, b)
 
 
+def test_switching_the_overlap_on_mid_sequence_waits_for_the_ordered_frames(pkg):
+    """A context that has been running ORDERED frames (inputs_ready = 0) switches to the cross-frame overlap without a host
+    synchronisation in between: the side stream, its events and the fourth colour plane are created by that frame, and its
+    temporal pass must still wait for the previous frame's kernels queued on the caller's stream (it reads their history).
+    Results must equal the fully ordered run bit for bit."""
+    import torch
+    W, H, N = 1920, 1080, 8
+    frames = [pkg.synth.render_frame(W, H, f, seed=43, moving=True) for f in range(4)]
+    tin = [torch.from_numpy(f[0]).cuda() for f in frames]
+    tg = [torch.from_numpy(f[1].view(np.uint8).reshape(-1)).cuda() for f in frames]
+    res = {}
+    for switch_at in (N, 3):            # N: never switched on
+        d = pkg.Denoiser(W, H, 0)
+        outs = [torch.empty((H, W, 3), dtype=torch.float32, device="cuda") for _ in range(N)]
+        stream = torch.cuda.Stream()
+        torch.cuda.synchronize()
+        with torch.cuda.stream(stream):
+            for k in range(N):
+                p = pkg.reference_defaults().set(temporal_enable=1, spatial_enable=1, inputs_ready=1 if k >= switch_at else 0)
+                d.denoise(outs[k], tin[k % 4], tg[k % 4], frames[k % 4][2], p, stream=stream)
+        d.sync()
+        res[switch_at] = ([o.cpu().numpy() for o in outs], d.read_state(0), d.read_state(2))
+        d.free()
+    for k in range(N):
+        assert np.array_equal(res[N][0][k], res[3][0][k]), f"frame {k} differs after switching the overlap on at frame 3"
+    assert np.array_equal(res[N][1], res[3][1]) and np.array_equal(res[N][2], res[3][2])
+
+
 def test_error_codes(pkg):
     import ctypes
     d = pkg.Denoiser(64, 64, 0)

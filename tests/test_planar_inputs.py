@@ -1,0 +1,128 @@
+"""SURVEY.md §8f row f1, second half: the AoS -> plane repack fused into the producer (svgf_planar_gbuffer /
+svgf_denoise_planar / svgf_synth_render_planar).  The planar path must give exactly what svgf_denoise gives on the same
+texels: goldens of the reference replayed through both, and the device producer writing planes against the same producer
+writing AoS texels."""
+import ctypes
+
+import numpy as np
+import pytest
+
+from conftest import golden_cases, load_golden, replay
+
+pytestmark = pytest.mark.gpu
+
+
+def _hip():
+    """The HIP runtime already loaded into this process (torch's), for plain host-to-device copies into raw pointers."""
+    for ln in open("/proc/self/maps"):
+        if "libamdhip64" in ln:
+            return ctypes.CDLL(ln.split()[-1])
+    raise RuntimeError("no HIP runtime loaded")
+
+
+class AosEngine:
+    def __init__(self, pkg, W, H):
+        self.d = pkg.Denoiser(W, H, device=0)
+
+    def reset(self):
+        self.d.reset()
+
+    def denoise(self, color, gbuffer, cam, p):
+        return self.d.denoise_host(color, gbuffer, cam, p)
+
+    def free(self):
+        self.d.free()
+
+
+class PlanarEngine(AosEngine):
+    """Splits the texels on the host, copies the fields into the context's current-frame planes (what a plane-writing
+    producer does on the device) and runs svgf_denoise_planar."""
+
+    def denoise(self, color, gbuffer, cam, p):
+        import torch
+        hip = _hip()
+        hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+        g = self.d.planar_gbuffer()
+        gb = np.ascontiguousarray(gbuffer).reshape(-1)
+        for dst, arr in ((g.normal, gb["normal"].astype(np.float32)), (g.position, gb["position"].astype(np.float32)),
+                         (g.geom_id, gb["geomId"].astype(np.int32)), (g.albedo, (gb["albedo"] * gb["ialbedo"]).astype(np.float32))):
+            arr = np.ascontiguousarray(arr)
+            assert hip.hipMemcpy(dst, arr.ctypes.data, arr.nbytes, 1) == 0
+        H, W = self.d.height, self.d.width
+        tin = torch.from_numpy(np.ascontiguousarray(color, dtype=np.float32)).cuda()
+        out = torch.empty((H, W, 3), dtype=torch.float32, device="cuda")
+        self.d.denoise_planar(out, tin, cam, p)
+        torch.cuda.synchronize()
+        return out.cpu().numpy().reshape(np.asarray(color).shape)
+
+
+@pytest.mark.parametrize("name", [c for c in golden_cases() if c.startswith(("full_", "temporal_", "atrous_synth", "atrous_nan", "atrous_rand64"))])
+def test_planar_path_is_bit_identical_to_the_aos_path_on_the_goldens(pkg, name):
+    z, runs = load_golden(name)
+    W, H = int(z["W"]), int(z["H"])
+    for tag in runs:
+        if int(z[f"call_params_{tag}"][0][8]) > 7:
+            continue
+        a, b = AosEngine(pkg, W, H), PlanarEngine(pkg, W, H)
+        ra, rb = replay(pkg, a, z, tag), replay(pkg, b, z, tag)
+        a.free(); b.free()
+        assert np.array_equal(ra, rb, equal_nan=True), f"{name}:{tag}: the planar path differs from the AoS path"
+
+
+def test_device_producer_writing_planes_equals_the_one_writing_texels(pkg):
+    """svgf_synth_render_planar -> svgf_denoise_planar against svgf_synth_render -> svgf_denoise, 6 moving frames at 640x360,
+    sepcolor + addcolor on so that the albedo plane is exercised: bit-identical outputs and history."""
+    import torch
+    W, H, N = 640, 360, 6
+    p = pkg.reference_defaults().set(temporal_enable=1, spatial_enable=1, sepcolor=1, addcolor=1)
+    rgb = torch.empty((H, W, 3), dtype=torch.float32, device="cuda")
+    gbt = torch.empty((H * W * 52,), dtype=torch.uint8, device="cuda")
+    res = {}
+    for planar in (False, True):
+        d = pkg.Denoiser(W, H, 0)
+        outs = []
+        out = torch.empty((H, W, 3), dtype=torch.float32, device="cuda")
+        for f in range(N):
+            cam = pkg.synth.camera_for_frame(f, True)
+            if planar:
+                pkg.binding.synth_render_planar(rgb, d.planar_gbuffer(), W, H, cam, f, seed=77)
+                d.denoise_planar(out, rgb, cam, p)
+            else:
+                pkg.binding.synth_render(rgb, gbt, W, H, cam, f, seed=77)
+                d.denoise(out, rgb, gbt, cam, p)
+            torch.cuda.synchronize()
+            outs.append(out.cpu().numpy().copy())
+        res[planar] = (outs, d.read_state(0), d.read_state(1), d.read_state(2))
+        d.free()
+    for f in range(N):
+        assert np.array_equal(res[False][0][f], res[True][0][f]), f"frame {f}"
+    for a, b in zip(res[False][1:], res[True][1:]):
+        assert np.array_equal(a, b)
+
+
+def test_planar_and_aos_frames_alternate_on_one_context(pkg):
+    """The planes rotate with the history whichever entry point fed them: alternating frames equal an all-AoS run."""
+    import torch
+    W, H, N = 320, 200, 6
+    p = pkg.reference_defaults().set(temporal_enable=1, spatial_enable=1)
+    rgb = torch.empty((H, W, 3), dtype=torch.float32, device="cuda")
+    gbt = torch.empty((H * W * 52,), dtype=torch.uint8, device="cuda")
+    out = torch.empty((H, W, 3), dtype=torch.float32, device="cuda")
+    res = {}
+    for mixed in (False, True):
+        d = pkg.Denoiser(W, H, 0)
+        outs = []
+        for f in range(N):
+            cam = pkg.synth.camera_for_frame(f, True)
+            if mixed and f % 2 == 1:
+                pkg.binding.synth_render_planar(rgb, d.planar_gbuffer(), W, H, cam, f, seed=5)
+                d.denoise_planar(out, rgb, cam, p)
+            else:
+                pkg.binding.synth_render(rgb, gbt, W, H, cam, f, seed=5)
+                d.denoise(out, rgb, gbt, cam, p)
+            torch.cuda.synchronize()
+            outs.append(out.cpu().numpy().copy())
+        res[mixed] = outs
+        d.free()
+    for f in range(N):
+        assert np.array_equal(res[False][f], res[True][f]), f"frame {f}"
