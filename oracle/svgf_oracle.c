@@ -493,11 +493,23 @@ void svgf_oracle_reset(oracle_ctx *c) { if (c) zero_history(c); }
 void svgf_oracle_set_threads(oracle_ctx *c, int n) { if (c) c->nthreads = n > 0 ? n : 1; }
 void svgf_oracle_set_variance_mode(oracle_ctx *c, int m) { if (c) c->variance_mode = m; }
 
+/* The reference's device-to-device copies (:366,391,396-398).  Row blocks dealt statically to the same threads that
+ * process those rows in the kernels above: no serial section, and on a multi-socket host every page is first touched by
+ * (hence placed next to) the thread that will read it. */
+static void par_copy(void *dst, const void *src, size_t bytes_per_row, int rows, int nthreads)
+{
+    int y;
+#pragma omp parallel for schedule(static) num_threads(nthreads > 0 ? nthreads : 1)
+    for (y = 0; y < rows; y++)
+        memcpy((char *)dst + (size_t)y * bytes_per_row, (const char *)src + (size_t)y * bytes_per_row, bytes_per_row);
+}
+
 int svgf_oracle_denoise(oracle_ctx *c, float *out, const float *in, const SvgfGBufferTexel *g,
                         const SvgfCamera *cam, const SvgfParams *p)
 {
     const int W = c->W, H = c->H;
     const size_t n = (size_t)W * H;
+    const int nt = c->nthreads;
 
     /* 1) temporal accumulation or constant variance (:360-371) */
     if (p->temporal_enable) {
@@ -508,12 +520,12 @@ int svgf_oracle_denoise(oracle_ctx *c, float *out, const float *in, const SvgfGB
         if (p->spatial_variance_frames > 0)
             svgf_oracle_spatial_variance(c->variance, c->moment_acc, c->history_length_update, g, W, H,
                                          p->spatial_variance_frames, c->nthreads);
-        memcpy(c->color_history, c->color_acc, n * 3 * sizeof(float));
+        par_copy(c->color_history, c->color_acc, (size_t)W * 3 * sizeof(float), H, nt);
     } else {
         for (size_t k = 0; k < n; k++) c->variance[k] = 10.0f;
-        memcpy(c->color_history, in, n * 3 * sizeof(float));
+        par_copy(c->color_history, in, (size_t)W * 3 * sizeof(float), H, nt);
     }
-    memcpy(c->variance_temporal, c->variance, n * sizeof(float));
+    par_copy(c->variance_temporal, c->variance, (size_t)W * sizeof(float), H, nt);
 
     /* 2) debug views, pass-through, or the a-trous cascade (:373-394) */
     if (p->right_view_option == 1) {
@@ -533,18 +545,18 @@ int svgf_oracle_denoise(oracle_ctx *c, float *out, const float *in, const SvgfGB
                 svgf_oracle_atrous(src, dst, c->variance, c->variance, g, W, H, lexp, level == p->atrous_nlevel,
                                    p->sigma_l, p->sigma_n, p->sigma_x, p->blur_variance, addcolor, 1, 1);
             } else {
-                memcpy(c->variance_tmp, c->variance, n * sizeof(float));
+                par_copy(c->variance_tmp, c->variance, (size_t)W * sizeof(float), H, nt);
                 svgf_oracle_atrous(src, dst, c->variance_tmp, c->variance, g, W, H, lexp, level == p->atrous_nlevel,
                                    p->sigma_l, p->sigma_n, p->sigma_x, p->blur_variance, addcolor, 0, c->nthreads);
             }
-            if (level == p->history_level) memcpy(c->color_history, dst, n * 3 * sizeof(float));
+            if (level == p->history_level) par_copy(c->color_history, dst, (size_t)W * 3 * sizeof(float), H, nt);
         }
     }
 
     /* 3) history rotation — executed in every mode (:396-399) */
-    memcpy(c->gbuffer_prev, g, n * sizeof(SvgfGBufferTexel));
-    memcpy(c->moment_history, c->moment_acc, n * 2 * sizeof(float));
-    memcpy(c->history_length, c->history_length_update, n * sizeof(int));
+    par_copy(c->gbuffer_prev, g, (size_t)W * sizeof(SvgfGBufferTexel), H, nt);
+    par_copy(c->moment_history, c->moment_acc, (size_t)W * 2 * sizeof(float), H, nt);
+    par_copy(c->history_length, c->history_length_update, (size_t)W * sizeof(int), H, nt);
     svgf_oracle_view_matrix(cam, c->view_prev);
     return 0;
 }
