@@ -14,9 +14,8 @@
 // Wave specialisation.  Measured on MI355X (profiles/r01_strip_phase_timeline.log): with every wave doing
 // load -> math -> store -> barrier in lockstep, the 25-tap math ran VALU-saturated but only ~45 % of the time; the
 // rest was vector-memory issue, LDS staging and barrier skew that nothing overlapped.  The workgroup is therefore
-// TX*ROWS compute threads + three loader groups (2 waves each) that take turns: a loader fetches the next ROWS lattice
-// rows (and the two
-// full-resolution neighbour rows the 3x3 variance pre-blur needs) while the compute waves evaluate taps, converts
+// TX*ROWS compute threads + two loader groups (2 waves each) that take turns: a loader fetches the next ROWS lattice
+// rows (and the two full-resolution neighbour rows the 3x3 variance pre-blur needs) while the compute waves evaluate taps, converts
 // them to the LDS layout and publishes them at the single barrier that ends the iteration.  Compute waves issue no
 // vector-memory loads at all.
 //

@@ -32,7 +32,7 @@ extern "C" {
 #endif
 
 #define SVGF_VERSION_MAJOR 0
-#define SVGF_VERSION_MINOR 3
+#define SVGF_VERSION_MINOR 4
 
 /* ---- error codes (every entry point returns one of these; the library never exits) ---- */
 #define SVGF_OK                 0

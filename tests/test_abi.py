@@ -40,7 +40,15 @@ def test_params_default_matches_reference_ui_defaults(pkg):
     q = pkg.reference_defaults()        # reference src/main.cpp:49-62
     for name, _ in pkg.SvgfParams._fields_[:15]:
         assert getattr(p, name) == pytest.approx(getattr(q, name)), name
-    assert lib.svgf_version() == (0 << 16) | 3
+    assert lib.svgf_version() == (0 << 16) | 4
+
+
+def test_params_size_is_exported_and_checked(pkg):
+    """SvgfParams grows at its tail between ABI versions (0.2: 72 bytes, 0.3: 80) and svgf_denoise reads all of it: the
+    library says how large ITS struct is so that a binding can refuse a mismatch at load time (binding.load_library does)."""
+    lib = pkg.load_library()
+    assert lib.svgf_params_sizeof() == ctypes.sizeof(pkg.SvgfParams) == 80
+    assert lib.svgf_planar_gbuffer(None, None) == -1 and lib.svgf_denoise_planar(None, None, None, None, None, None) == -1
 
 
 def test_error_paths_without_gpu(pkg):

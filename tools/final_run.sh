@@ -1,15 +1,16 @@
 #!/bin/bash
-# Evidence run for profiles/ (round 2): tests, bench lines (same command the driver uses + the long run), rocprofv3 kernel
+# Evidence run for profiles/ (round 3): tests, bench lines (same command the driver uses + the long run), rocprofv3 kernel
 # stats of the bench command, PMC passes (SQ + HBM traffic, FETCH and WRITE in separate passes as MI355X_MICROARCH.md
-# prescribes).  Run on the GPU box:  bash tools/final_run.sh   -> everything lands under gpurun_out/final/
+# prescribes).  Run on the GPU box:  bash tools/final_run.sh   -> everything lands under gpurun_out/final_r03/
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
-O=$R/gpurun_out/final
+O=$R/gpurun_out/final_r03
 mkdir -p $O
 cd $R
 python -m pytest tests -m gpu -q 2>&1 | tail -3 > $O/gpu_tests.txt
 python bench.py --steps 20 --warmup 5 > $O/bench_line_driver_cmd.json 2> $O/bench_driver_cmd.err
 python bench.py --no-cpu-baseline > $O/bench_line.json 2>/dev/null
 python bench.py --no-cpu-baseline --overlap > $O/bench_line_overlap.json 2>/dev/null
+python bench.py --no-cpu-baseline --planar-inputs > $O/bench_line_planar_inputs.json 2>/dev/null
 python bench.py --no-cpu-baseline --config 1080p-moving > $O/bench_line_1080p_moving.json 2>/dev/null
 python bench.py --no-cpu-baseline --config 4k-static > $O/bench_line_4k_static.json 2>/dev/null
 python bench.py --config config1 > $O/bench_line_config1.json 2>/dev/null
@@ -30,5 +31,11 @@ rm -rf $O/pmc_hbm
 SVGF_NO_VARIANCE_PLANE=1 rocprofv3 -i $R/tools/pmc_traffic.txt -d $O/pmc_hbm2 -o p --output-format csv -- python $R/tools/probe.py --variants 0 --frames 6 > /dev/null 2>&1
 python $R/tools/pmc_summary.py $O/pmc_hbm2 "atrous" > $O/pmc_hbm_no_variance_plane.txt
 rm -rf $O/pmc_hbm2
+rocprofv3 --kernel-trace --stats -d $O/prof2 -o p --output-format csv -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --planar-inputs > /dev/null 2>&1
+cp $(find $O/prof2 -name "*kernel_stats.csv" | head -1) $O/rocprofv3_kernel_stats_bench_planar.csv 2>/dev/null
+rm -rf $O/prof2
+rocprofv3 -i $R/tools/pmc_traffic.txt -d $O/pmc_hbm3 -o p --output-format csv -- python $R/bench.py --steps 12 --warmup 3 --no-cpu-baseline --planar-inputs --min-warmup-seconds 0.1 > /dev/null 2>&1
+python $R/tools/pmc_summary.py $O/pmc_hbm3 "k_temporal" > $O/pmc_hbm_planar_temporal.txt
+rm -rf $O/pmc_hbm3
 rocminfo | grep -E "Marketing Name|Compute Unit|Max Clock" | head -12 > $O/gpu_box.txt; nproc >> $O/gpu_box.txt; grep -m1 "model name" /proc/cpuinfo >> $O/gpu_box.txt
 ls -la $O
