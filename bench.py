@@ -68,13 +68,37 @@ def physical_cores():
     return os.cpu_count() or 1, ""
 
 
+def cgroup_cpu_quota():
+    """CPUs' worth of time this container may use (cgroup v2 cpu.max / v1 cfs quota), or None when unlimited."""
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            return max(1, int(int(q) / int(per)))
+    except (OSError, ValueError):
+        pass
+    try:
+        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        if q > 0:
+            return max(1, q // per)
+    except (OSError, ValueError):
+        pass
+    return None
+
+
 def cpu_baseline(pkg, frames, params, budget_s=25.0, threads=None, what="full-SVGF", all_cores=True):
     """CPU oracle (oracle/svgf_oracle.c, OpenMP) on the same workload, bounded sample.  Threads are bound one per physical
     core (OMP_PLACES=cores, OMP_PROC_BIND=close, set in main() before libgomp starts) and rows are dealt in static blocks, so
     that the all-cores figure is not the SMT + unbound one of round 2 (slower than 64 threads)."""
     orc = ge.load_oracle()
     cores, cpu_model = physical_cores()
-    threads = min(cores, 64) if threads is None else threads
+    quota = cgroup_cpu_quota()
+    # The GPU boxes of this pool are containers with a CFS quota (cpu.max = 16 CPUs on a 2 x 64-core host): threads beyond the
+    # quota are throttled, which is what made round 2's "all cores" figure slower than its 64-thread one
+    # (tools/experiments/exp_cpu_scaling.py: 16 threads 8.7, 24: 10.4, 64: 5.2-6.5, 128: 3.5-4.2 Mpix/s).  The leg uses as many
+    # threads as the container can actually run.
+    usable = min(cores, quota) if quota else cores
+    threads = min(usable, 64) if threads is None else threads
     o = orc.Oracle(pkg, W, H, threads=threads)
     t_all, n = 0.0, 0
     t_start = time.perf_counter()
@@ -90,10 +114,11 @@ def cpu_baseline(pkg, frames, params, budget_s=25.0, threads=None, what="full-SV
     o.free()
     res = {"value": round(W * H / (t_all / n) / 1e6, 3), "unit": "Mpixels/s", "cores": threads, "kind": "port",
            "sample": f"{n} steady-state frames of the same {W}x{H} {what} workload, oracle/svgf_oracle.c "
-                     f"(gcc -O2, OpenMP static row blocks, threads bound to cores; {threads} threads of {cores} physical cores, "
-                     f"{os.cpu_count()} hardware threads, {cpu_model})"}
-    if all_cores and cores > threads:        # north_star: "the same box's host cores" — every physical core, next to the 64-thread figure
-        oa = orc.Oracle(pkg, W, H, threads=cores)
+                     f"(gcc -O2, OpenMP static row blocks, threads bound to cores; {threads} threads; host: {cores} physical cores, "
+                     f"{os.cpu_count()} hardware threads, {cpu_model}; container CPU quota: {quota if quota else 'none'})",
+           "host": {"physical_cores": cores, "hardware_threads": os.cpu_count(), "cpu_model": cpu_model, "cgroup_cpu_quota": quota}}
+    if all_cores and usable > threads:       # north_star: "the same box's host cores" — every core the container may use
+        oa = orc.Oracle(pkg, W, H, threads=usable)
         ts = []
         for f in range(3):
             c, g, cam = frames[f % len(frames)]
@@ -102,8 +127,8 @@ def cpu_baseline(pkg, frames, params, budget_s=25.0, threads=None, what="full-SV
             if f >= 1:
                 ts.append(time.perf_counter() - t0)
         oa.free()
-        res["all_cores"] = {"value": round(W * H / (sum(ts) / len(ts)) / 1e6, 3), "unit": "Mpixels/s", "cores": cores,
-                            "sample": f"{len(ts)} steady-state frames, one bound thread on each of the {cores} physical cores"}
+        res["all_cores"] = {"value": round(W * H / (sum(ts) / len(ts)) / 1e6, 3), "unit": "Mpixels/s", "cores": usable,
+                            "sample": f"{len(ts)} steady-state frames, one bound thread on each of the {usable} usable physical cores"}
     return res
 
 

@@ -442,55 +442,99 @@ struct oracle_ctx {
     SvgfGBufferTexel *gbuffer_prev;
     float *variance, *variance_tmp;     /* variance_tmp: snapshot for ORACLE_VARIANCE_SNAPSHOT */
     float *variance_temporal;           /* copy of variance right after the temporal pass (state inspection) */
+    float *in_local;                    /* the call's inputs, copied in row blocks by the threads that read them */
+    SvgfGBufferTexel *g_local;          /* (placement only: on a two-socket host the caller's arrays sit on one node) */
 };
+
+/* rows zeroed by the thread that will later process them (static blocks): first touch places the pages next to it */
+static void par_zero(void *dst, size_t bytes_per_row, int rows, int nthreads)
+{
+    int y;
+#pragma omp parallel for schedule(static) num_threads(nthreads > 0 ? nthreads : 1)
+    for (y = 0; y < rows; y++) memset((char *)dst + (size_t)y * bytes_per_row, 0, bytes_per_row);
+}
 
 static void zero_history(oracle_ctx *c)
 {
-    size_t n = (size_t)c->W * c->H;
-    memset(c->history_length, 0, n * sizeof(int));
-    memset(c->history_length_update, 0, n * sizeof(int));
-    memset(c->moment_history, 0, n * 2 * sizeof(float));
-    memset(c->moment_acc, 0, n * 2 * sizeof(float));
-    memset(c->variance, 0, n * sizeof(float));
-    memset(c->color_history, 0, n * 3 * sizeof(float));
-    memset(c->color_acc, 0, n * 3 * sizeof(float));
-    memset(c->gbuffer_prev, 0, n * sizeof(SvgfGBufferTexel));
-    memset(c->variance_temporal, 0, n * sizeof(float));
+    const size_t W = (size_t)c->W;
+    const int H = c->H, nt = c->nthreads;
+    par_zero(c->history_length, W * sizeof(int), H, nt);
+    par_zero(c->history_length_update, W * sizeof(int), H, nt);
+    par_zero(c->moment_history, W * 2 * sizeof(float), H, nt);
+    par_zero(c->moment_acc, W * 2 * sizeof(float), H, nt);
+    par_zero(c->variance, W * sizeof(float), H, nt);
+    par_zero(c->color_history, W * 3 * sizeof(float), H, nt);
+    par_zero(c->color_acc, W * 3 * sizeof(float), H, nt);
+    par_zero(c->gbuffer_prev, W * sizeof(SvgfGBufferTexel), H, nt);
+    par_zero(c->variance_temporal, W * sizeof(float), H, nt);
+}
+
+static void free_planes(oracle_ctx *c)
+{
+    free(c->temp[0]); free(c->temp[1]); free(c->history_length); free(c->history_length_update);
+    free(c->moment_history); free(c->moment_acc); free(c->color_history); free(c->color_acc);
+    free(c->gbuffer_prev); free(c->variance); free(c->variance_tmp); free(c->variance_temporal);
+    free(c->in_local); free(c->g_local);
+}
+
+/* malloc, then zeroed in parallel by c->nthreads threads: the state keeps the reference's all-zero start (denoiseInit's
+ * cudaMemset, :37-59) and every page is first touched by the thread that owns its rows */
+static void alloc_planes(oracle_ctx *c)
+{
+    const size_t W = (size_t)c->W, n = W * c->H;
+    const int H = c->H, nt = c->nthreads;
+    c->temp[0] = (float *)malloc(n * 3 * sizeof(float));
+    c->temp[1] = (float *)malloc(n * 3 * sizeof(float));
+    c->history_length = (int *)malloc(n * sizeof(int));
+    c->history_length_update = (int *)malloc(n * sizeof(int));
+    c->moment_history = (float *)malloc(n * 2 * sizeof(float));
+    c->moment_acc = (float *)malloc(n * 2 * sizeof(float));
+    c->color_history = (float *)malloc(n * 3 * sizeof(float));
+    c->color_acc = (float *)malloc(n * 3 * sizeof(float));
+    c->gbuffer_prev = (SvgfGBufferTexel *)malloc(n * sizeof(SvgfGBufferTexel));
+    c->variance = (float *)malloc(n * sizeof(float));
+    c->variance_tmp = (float *)malloc(n * sizeof(float));
+    c->variance_temporal = (float *)malloc(n * sizeof(float));
+    c->in_local = (float *)malloc(n * 3 * sizeof(float));
+    c->g_local = (SvgfGBufferTexel *)malloc(n * sizeof(SvgfGBufferTexel));
+    par_zero(c->temp[0], W * 3 * sizeof(float), H, nt);
+    par_zero(c->temp[1], W * 3 * sizeof(float), H, nt);
+    par_zero(c->variance_tmp, W * sizeof(float), H, nt);
+    par_zero(c->in_local, W * 3 * sizeof(float), H, nt);
+    par_zero(c->g_local, W * sizeof(SvgfGBufferTexel), H, nt);
+    zero_history(c);
 }
 
 oracle_ctx *svgf_oracle_create(int W, int H)
 {
     if (W <= 0 || H <= 0) return NULL;
     oracle_ctx *c = (oracle_ctx *)calloc(1, sizeof(*c));
-    size_t n = (size_t)W * H;
     c->W = W; c->H = H; c->nthreads = 1; c->variance_mode = ORACLE_VARIANCE_SNAPSHOT;
     for (int k = 0; k < 16; k++) c->view_prev[k] = (k % 5 == 0) ? 1.0f : 0.0f;
-    c->temp[0] = (float *)calloc(n * 3, sizeof(float));
-    c->temp[1] = (float *)calloc(n * 3, sizeof(float));
-    c->history_length = (int *)calloc(n, sizeof(int));
-    c->history_length_update = (int *)calloc(n, sizeof(int));
-    c->moment_history = (float *)calloc(n * 2, sizeof(float));
-    c->moment_acc = (float *)calloc(n * 2, sizeof(float));
-    c->color_history = (float *)calloc(n * 3, sizeof(float));
-    c->color_acc = (float *)calloc(n * 3, sizeof(float));
-    c->gbuffer_prev = (SvgfGBufferTexel *)calloc(n, sizeof(SvgfGBufferTexel));
-    c->variance = (float *)calloc(n, sizeof(float));
-    c->variance_tmp = (float *)calloc(n, sizeof(float));
-    c->variance_temporal = (float *)calloc(n, sizeof(float));
+    alloc_planes(c);
     return c;
 }
 
 void svgf_oracle_destroy(oracle_ctx *c)
 {
     if (!c) return;
-    free(c->temp[0]); free(c->temp[1]); free(c->history_length); free(c->history_length_update);
-    free(c->moment_history); free(c->moment_acc); free(c->color_history); free(c->color_acc);
-    free(c->gbuffer_prev); free(c->variance); free(c->variance_tmp); free(c->variance_temporal);
+    free_planes(c);
     free(c);
 }
 
 void svgf_oracle_reset(oracle_ctx *c) { if (c) zero_history(c); }
-void svgf_oracle_set_threads(oracle_ctx *c, int n) { if (c) c->nthreads = n > 0 ? n : 1; }
+/* Changing the thread count re-creates the planes (contents preserved would need a copy: the only caller sets it right after
+ * svgf_oracle_create, before the first frame, so the state is the all-zero start either way) so that they are first touched
+ * by the threads that will work on them. */
+void svgf_oracle_set_threads(oracle_ctx *c, int n)
+{
+    if (!c) return;
+    n = n > 0 ? n : 1;
+    if (n == c->nthreads) return;
+    c->nthreads = n;
+    free_planes(c);
+    alloc_planes(c);
+}
 void svgf_oracle_set_variance_mode(oracle_ctx *c, int m) { if (c) c->variance_mode = m; }
 
 /* The reference's device-to-device copies (:366,391,396-398).  Row blocks dealt statically to the same threads that
@@ -510,6 +554,11 @@ int svgf_oracle_denoise(oracle_ctx *c, float *out, const float *in, const SvgfGB
     const int W = c->W, H = c->H;
     const size_t n = (size_t)W * H;
     const int nt = c->nthreads;
+    /* inputs next to the threads that read them (taps reach at most 64 rows beyond a thread's own block) */
+    par_copy(c->in_local, in, (size_t)W * 3 * sizeof(float), H, nt);
+    par_copy(c->g_local, g, (size_t)W * sizeof(SvgfGBufferTexel), H, nt);
+    in = c->in_local;
+    g = c->g_local;
 
     /* 1) temporal accumulation or constant variance (:360-371) */
     if (p->temporal_enable) {
