@@ -98,7 +98,11 @@ __global__ __launch_bounds__(NT) void k_atrous_lane(AtrousArgs a, LaneGeom gm)
     constexpr int S = 1 << LOG2S;
     constexpr int WPP = NWC / S;                 // waves per x-phase
     constexpr int M = LOUT * WPP + 4;            // lattice columns per phase in the ring (2 halo either side)
-    constexpr int MP = (M * 12 % 64 == 0) ? M + 1 : M;   // padded so that consecutive phases do not start on the same LDS bank
+    // phase stride in records, padded so that (a) consecutive phases do not start on the same bank for the readers and (b) the
+    // loaders' 16-byte stores, which are served eight consecutive lanes = pixels at a time with banks counted mod 32, do not
+    // collide: with S = 4 those eight lanes are phases 0..3 of two lattice columns, and 124 * 12 = 16 (mod 32) put phases 0 / 2
+    // and 1 / 3 on the same banks (a third of the kernel's remaining conflict cycles); 126 * 12 = 8 (mod 32) spreads all eight
+    constexpr int MP = (S == 4) ? M + 2 : ((M * 12 % 64 == 0) ? M + 1 : M);
     constexpr int RW = S * M;                    // staged pixel columns = TXO + 4S
     constexpr int ROWB = S * MP * PXB;           // bytes per ring row
     constexpr int BM = (BW + S - 1) / S;         // pre-blur lattice columns per phase
@@ -589,8 +593,10 @@ __global__ __launch_bounds__(NT) void k_atrous_lane(AtrousArgs a, LaneGeom gm)
         const float *bl = blur + (it & 1) * BLUR_BUF;
         const float m0 = bl[be_l], m1 = bl[be_c], m2 = bl[be_r];
         const float p0 = bl[BLUR_ROW + be_l], p1 = bl[BLUR_ROW + be_c], p2 = bl[BLUR_ROW + be_r];
-        const float c0v = *reinterpret_cast<const float *>(ringrow + off_l);
-        const float c2v = *reinterpret_cast<const float *>(ringrow + off_r);
+        // variance of the row neighbours x-1, x+1 (other x-phases): read as their whole C slot — a b128 is conflict-free at
+        // the 48-byte lane stride, a 4-byte read is 4-way conflicted (lanes 8 apart share a bank)
+        const float c0v = reinterpret_cast<const v4f *>(ringrow + off_l - 12)->w;
+        const float c2v = reinterpret_cast<const v4f *>(ringrow + off_r - 12)->w;
         ColRow r0;
         GeoRow g1;
         if (flip) load_geo(g1, bo + 1); else load_col(r0, bo - 2);       // the first tap row of this wave's stage order
@@ -755,7 +761,7 @@ __global__ __launch_bounds__(NT) void k_atrous_lane(AtrousArgs a, LaneGeom gm)
 template <int LOG2S, bool HASVAR>
 hipError_t launch_lane_cfg(const AtrousArgs &a, hipStream_t s)
 {
-    constexpr int S = 1 << LOG2S, M = LOUT * (NWC / S) + 4, MP = (M * 12 % 64 == 0) ? M + 1 : M, BM = (BW + S - 1) / S;
+    constexpr int S = 1 << LOG2S, M = LOUT * (NWC / S) + 4, MP = (S == 4) ? M + 2 : ((M * 12 % 64 == 0) ? M + 1 : M), BM = (BW + S - 1) / S;
     const size_t lds = (size_t)R * S * MP * PXB + (size_t)2 * 2 * S * BM * 4 + 16;
     static SvgfLaunchCache cache;
     int dev_id = 0;
