@@ -88,14 +88,14 @@ def cgroup_cpu_quota():
 
 def cpu_baseline(pkg, frames, params, budget_s=25.0, threads=None, what="full-SVGF", all_cores=True):
     """CPU oracle (oracle/svgf_oracle.c, OpenMP) on the same workload, bounded sample.  Threads are bound one per physical
-    core (OMP_PLACES=cores, OMP_PROC_BIND=close, set in main() before libgomp starts) and rows are dealt in static blocks, so
+    core (OMP_PLACES=cores, OMP_PROC_BIND=spread, set in main() before libgomp starts) and rows are dealt in static blocks, so
     that the all-cores figure is not the SMT + unbound one of round 2 (slower than 64 threads)."""
     orc = ge.load_oracle()
     cores, cpu_model = physical_cores()
     quota = cgroup_cpu_quota()
     # The GPU boxes of this pool are containers with a CFS quota (cpu.max = 16 CPUs on a 2 x 64-core host): threads beyond the
     # quota are throttled, which is what made round 2's "all cores" figure slower than its 64-thread one
-    # (tools/experiments/exp_cpu_scaling.py: 16 threads 8.7, 24: 10.4, 64: 5.2-6.5, 128: 3.5-4.2 Mpix/s).  The leg uses as many
+    # (tests/cpu_oracle_thread_scaling.py: 16 threads 8.7, 24: 10.4, 64: 5.2-6.5, 128: 3.5-4.2 Mpix/s).  The leg uses as many
     # threads as the container can actually run.
     usable = min(cores, quota) if quota else cores
     threads = min(usable, 64) if threads is None else threads
@@ -162,7 +162,7 @@ def main():
 
     # the CPU-baseline leg: one OpenMP thread per physical core, pinned (read by libgomp when the oracle library is loaded)
     os.environ.setdefault("OMP_PLACES", "cores")
-    os.environ.setdefault("OMP_PROC_BIND", "close")
+    os.environ.setdefault("OMP_PROC_BIND", "spread")     # one thread per core, spread over the CCDs: the oracle lives in L3 (close: 5.2, spread: 8.7 Mpix/s at 16 threads)
 
     import torch
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:

@@ -1,6 +1,6 @@
-"""Thread scaling of the CPU oracle (bench.py's cpu_baseline leg) on this host: Mpixels/s at 1920x1080 full SVGF."""
+"""Thread scaling of the CPU oracle (test infrastructure; what bench.py's cpu_baseline leg times) on this host: Mpixels/s at 1920x1080 full SVGF.
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import __graft_entry__ as ge
 pkg = ge.load_package(); orc = ge.load_oracle()
