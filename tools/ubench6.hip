@@ -78,6 +78,20 @@
     "ds_read_b128 v[48:51], v56 offset:48\n" "v_fma_f32 v16, v32, v33, v16\n v_fma_f32 v17, v32, v33, v17\n v_fma_f32 v18, v32, v33, v18\n v_fma_f32 v19, v32, v33, v19\n v_fma_f32 v20, v32, v33, v20\n v_fma_f32 v21, v32, v33, v21\n v_fma_f32 v22, v32, v33, v22\n v_fma_f32 v23, v32, v33, v23\n" \
     "s_waitcnt lgkmcnt(0)\n"
 
+// what a scalar instruction costs the wave that issues it: 16 fma alone, then the same with an s_add / s_mul / s_cmp+s_cselect
+// between every two of them
+#define FMA2(a, b) "v_fma_f32 v" #a ", v32, v33, v" #a "\n v_fma_f32 v" #b ", v32, v33, v" #b "\n"
+#define VS16_ADD FMA2(8, 9) "s_add_i32 s20, s20, 1\n" FMA2(10, 11) "s_add_i32 s21, s21, 1\n" FMA2(12, 13) "s_add_i32 s20, s20, 1\n" FMA2(14, 15) "s_add_i32 s21, s21, 1\n" \
+                 FMA2(16, 17) "s_add_i32 s20, s20, 1\n" FMA2(18, 19) "s_add_i32 s21, s21, 1\n" FMA2(20, 21) "s_add_i32 s20, s20, 1\n" FMA2(22, 23) "s_add_i32 s21, s21, 1\n"
+#define VS16_MUL FMA2(8, 9) "s_mulk_i32 s20, 3\n" FMA2(10, 11) "s_mulk_i32 s21, 3\n" FMA2(12, 13) "s_mulk_i32 s20, 3\n" FMA2(14, 15) "s_mulk_i32 s21, 3\n" \
+                 FMA2(16, 17) "s_mulk_i32 s20, 3\n" FMA2(18, 19) "s_mulk_i32 s21, 3\n" FMA2(20, 21) "s_mulk_i32 s20, 3\n" FMA2(22, 23) "s_mulk_i32 s21, 3\n"
+#define VS16_4 FMA2(8, 9) "s_add_i32 s20, s20, 1\n s_cmp_lt_i32 s20, 6\n s_cselect_b32 s21, 0, -6\n s_add_i32 s20, s20, s21\n" FMA2(10, 11) "s_add_i32 s20, s20, 1\n s_cmp_lt_i32 s20, 6\n s_cselect_b32 s21, 0, -6\n s_add_i32 s20, s20, s21\n" \
+               FMA2(12, 13) "s_add_i32 s20, s20, 1\n s_cmp_lt_i32 s20, 6\n s_cselect_b32 s21, 0, -6\n s_add_i32 s20, s20, s21\n" FMA2(14, 15) "s_add_i32 s20, s20, 1\n s_cmp_lt_i32 s20, 6\n s_cselect_b32 s21, 0, -6\n s_add_i32 s20, s20, s21\n" \
+               FMA2(16, 17) "s_add_i32 s20, s20, 1\n s_cmp_lt_i32 s20, 6\n s_cselect_b32 s21, 0, -6\n s_add_i32 s20, s20, s21\n" FMA2(18, 19) "s_add_i32 s20, s20, 1\n s_cmp_lt_i32 s20, 6\n s_cselect_b32 s21, 0, -6\n s_add_i32 s20, s20, s21\n" \
+               FMA2(20, 21) "s_add_i32 s20, s20, 1\n s_cmp_lt_i32 s20, 6\n s_cselect_b32 s21, 0, -6\n s_add_i32 s20, s20, s21\n" FMA2(22, 23) "s_add_i32 s20, s20, 1\n s_cmp_lt_i32 s20, 6\n s_cselect_b32 s21, 0, -6\n s_add_i32 s20, s20, s21\n"
+#define VS16_WAIT FMA2(8, 9) "s_waitcnt lgkmcnt(0)\n" FMA2(10, 11) "s_waitcnt lgkmcnt(0)\n" FMA2(12, 13) "s_waitcnt lgkmcnt(0)\n" FMA2(14, 15) "s_waitcnt lgkmcnt(0)\n" \
+                  FMA2(16, 17) "s_waitcnt lgkmcnt(0)\n" FMA2(18, 19) "s_waitcnt lgkmcnt(0)\n" FMA2(20, 21) "s_waitcnt lgkmcnt(0)\n" FMA2(22, 23) "s_waitcnt lgkmcnt(0)\n"
+
 template <int OP>
 __global__ __launch_bounds__(1024) void k(unsigned long long *out, int reps, float seed)
 {
@@ -116,6 +130,10 @@ __global__ __launch_bounds__(1024) void k(unsigned long long *out, int reps, flo
             if (OP == 16) asm volatile(DPP8 DPP8 DPP8 DPP8 ::: CLOB);
             if (OP == 17) asm volatile(DPPROW8 DPPROW8 DPPROW8 DPPROW8 ::: CLOB);
             if (OP == 18) asm volatile(LDSMIX LDSMIX ::: CLOB, "memory");       // 32 fma + 4 ds_read_b128
+            if (OP == 19) asm volatile(VS16_ADD VS16_ADD ::: CLOB, "s20", "s21", "scc");
+            if (OP == 20) asm volatile(VS16_MUL VS16_MUL ::: CLOB, "s20", "s21", "scc");
+            if (OP == 21) asm volatile(VS16_4 VS16_4 ::: CLOB, "s20", "s21", "scc");
+            if (OP == 22) asm volatile(VS16_WAIT VS16_WAIT ::: CLOB, "memory");
         }
         t1 = __builtin_amdgcn_s_memtime();
     }
@@ -171,10 +189,14 @@ int main()
     run<6>("v_exp_f32 x32", 32);
     run<7>("v_sqrt_f32 x32", 32);
     run<8>("v_rcp_f32 x32", 32);
-    run<9>("tap mix: 1 exp + 6 fma interleaved (x4 = 28)", 56);
+    run<9>("tap mix: 1 exp + 6 fma interleaved (x4 = 28)", 28);
     run<10>("tap cluster: 4 exp then 24 fma (28)", 28);
     run<16>("v_mov_b32_dpp wave_shr/shl x32", 32);
     run<17>("v_mov_b32_dpp row_shr/shl x32", 32);
-    run<18>("32 fma + 4 ds_read_b128 (+wait) (count 36)", 72);
+    run<18>("32 fma + 4 ds_read_b128 (+wait) (count 38)", 38);
+    run<19>("32 fma + 16 s_add_i32 (per fma: count 32)", 32);
+    run<20>("32 fma + 16 s_mulk_i32 (per fma)", 32);
+    run<21>("32 fma + 16 x {add,cmp,cselect,add} (per fma)", 32);
+    run<22>("32 fma + 16 s_waitcnt (satisfied) (per fma)", 32);
     return 0;
 }
