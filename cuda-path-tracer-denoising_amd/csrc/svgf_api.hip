@@ -193,7 +193,8 @@ extern "C" int svgf_create(int device, int width, int height, svgf_ctx **out)
     // three colour planes serve the ordered path (history, source, destination); the fourth one, the side stream and its
     // events belong to the cross-frame overlap and are created when a frame first asks for it (ensure_overlap_resources)
     for (int k = 0; k < 3 && ok; k++) ok = hipMalloc((void **)&c->cv[k], c->n * sizeof(float4)) == hipSuccess;
-    for (int k = 0; k < 3 && ok; k++) ok = hipMalloc((void **)&c->vp[k], (size_t)(width + 2) * (height + 2) * sizeof(float)) == hipSuccess;
+    // (+64 bytes: the step-16/32 lane kernel reads the variance plane in 16-byte pieces that may end 8 bytes behind the last margin)
+    for (int k = 0; k < 3 && ok; k++) ok = hipMalloc((void **)&c->vp[k], (size_t)(width + 2) * (height + 2) * sizeof(float) + 64) == hipSuccess;
     for (int k = 0; k < 2 && ok; k++) {
         ok = ok && hipMalloc((void **)&c->nrm[k], c->n * 3 * sizeof(float)) == hipSuccess;
         ok = ok && hipMalloc((void **)&c->gid[k], c->n * sizeof(int)) == hipSuccess;
@@ -227,7 +228,7 @@ static int ensure_overlap_resources(svgf_ctx *c, hipStream_t s)
         HIPC(c, hipMemsetAsync(c->cv[3], 0, c->n * sizeof(float4), s));
     }
     if (!c->vp[3]) {
-        HIPC(c, hipMalloc((void **)&c->vp[3], (size_t)(c->W + 2) * (c->H + 2) * sizeof(float)));
+        HIPC(c, hipMalloc((void **)&c->vp[3], (size_t)(c->W + 2) * (c->H + 2) * sizeof(float) + 64));
         HIPC(c, hipMemsetAsync(c->vp[3], 0, (size_t)(c->W + 2) * (c->H + 2) * sizeof(float), s));
     }
     if (!c->ev_hist) HIPC(c, hipEventCreateWithFlags(&c->ev_hist, hipEventDisableTiming));
@@ -380,10 +381,16 @@ struct KernelTimer {   // brackets one launch with an event pair when profiling 
 // Auto selection between the two fast a-trous kernels for steps 2-8: the lane-marching kernel works on 480-column strips,
 // the strip kernel on 256-column strips; the lane kernel is ~5 % faster per computed column, so it is chosen unless its
 // strips would leave noticeably more columns outside the image (1920, 3840, 800: lane; 1280, 2560, 1000: strip).
-static bool lane_pays(int W)
+static bool lane_pays(int W, int step)
 {
-    const double util_lane = (double)W / (double)(((W + 479) / 480) * 480);
     const double util_strip = (double)W / (double)(((W + 255) / 256) * 256);
+    if (step >= 16) {
+        // chunked x-phases: a workgroup outputs 120 (step 16) or 60 (step 32) lattice columns of each of its 4 (8) phases
+        const int cols = (W + step - 1) / step, txl = (step == 16) ? 120 : 60;
+        const double util_lane = (double)cols / (double)(((cols + txl - 1) / txl) * txl);
+        return util_lane * 1.05 >= util_strip;
+    }
+    const double util_lane = (double)W / (double)(((W + 479) / 480) * 480);
     return util_lane * 1.05 >= util_strip;
 }
 
@@ -534,14 +541,17 @@ static int denoise_frame(svgf_ctx *c, void *out_rgb_dev, const void *in_rgb_dev,
             a.sigma_c = p->sigma_l; a.sigma_n = p->sigma_n; a.sigma_x = p->sigma_x;
             a.blur_variance = p->blur_variance ? 1 : 0;
             a.modulate = (last && p->sepcolor && p->addcolor) ? 1 : 0;
-            a.var = nullptr; a.var_dst = nullptr;
+            // pre-blur source of steps >= 16: the zero-margined 4-byte variance plane the producer level wrote next to its colour
+            // plane (see below); the lane kernel at those steps REQUIRES it (its loaders blur the variance from it)
+            a.var = (c->use_vplane && a.step >= 16 && ((c->vp_valid >> src) & 1u)) ? c->vp[src] : nullptr;
+            a.var_dst = nullptr;
             bool strip = false, lattice = false;
             if (p->kernel_variant != 1) {
                 strip = atrous_strip_supported(a);
                 lattice = !strip && p->kernel_variant != 2 && atrous_lattice_supported(a);     // steps 64, 128, ...
             }
             enum { K_LANE, K_STRIP, K_LATTICE, K_GATHER } which;
-            if (strip && atrous_lane_supported(a) && (p->kernel_variant == 4 || (p->kernel_variant == 0 && lane_pays(c->W)))) which = K_LANE;
+            if (strip && atrous_lane_supported(a) && (p->kernel_variant == 4 || (p->kernel_variant == 0 && lane_pays(c->W, a.step)))) which = K_LANE;
             else if (strip) which = K_STRIP;
             else if (lattice) which = K_LATTICE;
             else which = K_GATHER;
@@ -552,8 +562,8 @@ static int denoise_frame(svgf_ctx *c, void *out_rgb_dev, const void *in_rgb_dev,
             // the neighbouring rows are the sibling y-phases' own rows, already in L2: a plane would ADD 8 B/px (measured,
             // profiles/r02_pmc_hbm.txt), so those levels keep reading colour.w and only the level feeding a step-16 level
             // writes the plane.
+            if (which != K_LANE && which != K_STRIP) a.var = nullptr;
             if ((which == K_LANE || which == K_STRIP) && c->use_vplane) {
-                if (a.step >= 16 && ((c->vp_valid >> src) & 1u)) a.var = c->vp[src];
                 if (dst >= 0 && !last && a.step >= 8) a.var_dst = c->vp[dst];
             }
             if (dst >= 0) { if (a.var_dst) c->vp_valid |= 1u << dst; else c->vp_valid &= ~(1u << dst); }

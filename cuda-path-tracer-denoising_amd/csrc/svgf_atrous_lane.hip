@@ -92,24 +92,34 @@ __device__ __forceinline__ float lane_from(float v)
     return __builtin_bit_cast(float, x);
 }
 
-template <int LOG2S, bool HASVAR>
+// LOG2P < LOG2S (steps 16, 32): a workgroup's 8 waves hold only P = 4 (8) of the S x-phases — "chunks" of P adjacent pixels
+// every S pixels — and all the lattice columns of those phases that a wave can hold: at 1920 pixels 120 (60) columns per
+// phase = exactly two (one) waves of 60.  Everything downstream of the staging is unchanged (a wave is still 64 consecutive
+// lattice columns of one x-phase); what changes is (a) the pixel a staged column stands for, (b) the 3x3 variance pre-blur:
+// a centre's x-1 / x+1 neighbours lie in phases the workgroup may not stage, so for P < S the LOADER threads compute the
+// blurred variance of every pixel of the incoming output row from the producer's 4-byte variance plane (three rows x
+// {one dwordx4 + two dwords} per four pixels) and the compute lanes read one float instead of eight.
+template <int LOG2S, bool HASVAR, int LOG2P = LOG2S>
 __global__ __launch_bounds__(NT) void k_atrous_lane(AtrousArgs a, LaneGeom gm)
 {
     constexpr int S = 1 << LOG2S;
-    constexpr int WPP = NWC / S;                 // waves per x-phase
+    constexpr int P = 1 << LOG2P;                // x-phases held by one workgroup
+    constexpr bool CHUNKED = (P < S);
+    constexpr int WPP = NWC / P;                 // waves per x-phase
     constexpr int M = LOUT * WPP + 4;            // lattice columns per phase in the ring (2 halo either side)
     // phase stride in records, padded so that (a) consecutive phases do not start on the same bank for the readers and (b) the
     // loaders' 16-byte stores, which are served eight consecutive lanes = pixels at a time with banks counted mod 32, do not
     // collide: with S = 4 those eight lanes are phases 0..3 of two lattice columns, and 124 * 12 = 16 (mod 32) put phases 0 / 2
     // and 1 / 3 on the same banks (a third of the kernel's remaining conflict cycles); 126 * 12 = 8 (mod 32) spreads all eight
-    constexpr int MP = (S == 4) ? M + 2 : ((M * 12 % 64 == 0) ? M + 1 : M);
-    constexpr int RW = S * M;                    // staged pixel columns = TXO + 4S
-    constexpr int ROWB = S * MP * PXB;           // bytes per ring row
+    constexpr int MP = (P == 4) ? M + 2 : ((M * 12 % 64 == 0) ? M + 1 : M);
+    constexpr int RW = P * M;                    // staged pixel columns (= TXO + 4S when P == S)
+    constexpr int ROWB = P * MP * PXB;           // bytes per ring row
     constexpr int BM = (BW + S - 1) / S;         // pre-blur lattice columns per phase
     constexpr int RING_BYTES = R * ROWB;
     constexpr int BLUR_ROW = S * BM;             // floats per pre-blur row (phase-major)
-    constexpr int BLUR_BUF = 2 * BLUR_ROW;       // [y-1 | y+1]
-    static_assert(RW == TXO + 4 * S, "layout");
+    constexpr int BLUR_BUF = CHUNKED ? P * M : 2 * BLUR_ROW;      // [y-1 | y+1], or the blurred variance [phase][column]
+    constexpr int TXL = LOUT * WPP;              // lattice columns a workgroup outputs per phase
+    static_assert(CHUNKED || RW == TXO + 4 * S, "layout");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float *blur = reinterpret_cast<float *>(smem + RING_BYTES);           // [iteration parity][y-1 | y+1][phase][BM]
@@ -136,7 +146,14 @@ __global__ __launch_bounds__(NT) void k_atrous_lane(AtrousArgs a, LaneGeom gm)
     const int b0 = seg * gm.seg_rows;
     const int b1 = min(b0 + gm.seg_rows, nb);
     if (b0 >= b1) return;
-    const int x0 = strip * TXO;
+    const int x0 = strip * TXO;                  // P == S: first output column of the strip
+    // staged column xi = (lattice column c = xi / P, phase ph = xi % P) stands for image column (lbase + c) * S + pbase + ph
+    const int lbase = (CHUNKED ? (strip / (S / P)) : strip) * TXL - 2;
+    const int pbase = CHUNKED ? (strip % (S / P)) * P : 0;
+    auto xs_of = [&](int xi) {
+        if constexpr (!CHUNKED) return x0 - 2 * S + xi;
+        else return ((xi >> LOG2P) + lbase) * S + pbase + (xi & (P - 1));
+    };
     const int tid = threadIdx.x;
     // where the pre-blur rows come from: the zero-margined 4-byte variance plane of the source ((W+2) x (H+2), written by
     // the producer next to its colour plane) when there is one — contiguous dwords — else the .w of the 16-byte colour
@@ -179,7 +196,7 @@ __global__ __launch_bounds__(NT) void k_atrous_lane(AtrousArgs a, LaneGeom gm)
     auto slot_mod = [&](int br) { return (br - (b0 - 2)) % R; };
     auto ring_advance = [&]() { ring_b += 1; ring_base += 1; ring_base -= (ring_base >= R) ? R : 0; };
     // record of staged pixel column xi (0 .. RW-1) inside a ring row: phase-major
-    auto rec_of = [&](int xi) { return ((xi & (S - 1)) * MP + (xi >> LOG2S)) * PXB; };
+    auto rec_of = [&](int xi) { return ((xi & (P - 1)) * MP + (xi >> LOG2P)) * PXB; };
     // element of pre-blur pixel column xb (0 .. BW-1) inside a pre-blur row
     auto bel_of = [&](int xb) { return (xb & (S - 1)) * BM + (xb >> LOG2S); };
 
@@ -193,7 +210,7 @@ __global__ __launch_bounds__(NT) void k_atrous_lane(AtrousArgs a, LaneGeom gm)
             const int rr = idx / RW, xi = idx - rr * RW;
             const int br = br_first + rr;
             const int y = phase + (br << LOG2S);
-            const int xs = x0 - 2 * S + xi;
+            const int xs = xs_of(xi);
             const bool ok = (br >= 0) && (y < H) && (xs >= 0) && (xs < W);
             px[m].lds_off = (slot_mod(br) * ROWB + rec_of(xi)) | (ok ? 0 : (int)0x80000000);
             const unsigned q = (unsigned)min(max(y, 0), H - 1) * (unsigned)W + (unsigned)min(max(xs, 0), W - 1);
@@ -246,6 +263,46 @@ __global__ __launch_bounds__(NT) void k_atrous_lane(AtrousArgs a, LaneGeom gm)
         }
     };
 
+    // CHUNKED: the blurred variance (3x3 gaussian, out-of-image taps dropped and renormalised, :102-118) of the pixels of output
+    // row bo, four consecutive staged columns (one lattice column, phases ph0 .. ph0+3) per thread: from the zero-margined
+    // variance plane rows y-1, y, y+1 it needs pixels x .. x+3 (one dwordx4) and x-1, x+4 (two dwords).  Same expression as
+    // the compute lanes evaluate for P == S.
+    struct VB { float4 r[3]; float l[3], e[3]; };
+    auto vblur_load = [&](VB &v, int bo, int unit) {
+        const int xi0 = min(unit, RW / 4 - 1) * 4;
+        const int xq = min(max(xs_of(xi0), 0), W - 1);
+        const int y = phase + (bo << LOG2S);
+#pragma unroll
+        for (int d = 0; d < 3; d++) {
+            const char *rowp = vbase + (long)min(max(y + d - 1, -1), H) * (long)vys + (long)xq * 4;
+            v.r[d] = *reinterpret_cast<const float4 *>(rowp);
+            v.l[d] = *reinterpret_cast<const float *>(rowp - 4);
+            v.e[d] = *reinterpret_cast<const float *>(rowp + 16);
+        }
+    };
+    auto vblur_store = [&](const VB &v, int bo, int parity, int unit) {
+        if (unit >= RW / 4) return;
+        const int xi0 = unit * 4;
+        const int c = xi0 >> LOG2P, ph0 = xi0 & (P - 1);
+        const int x = xs_of(xi0), y = phase + (bo << LOG2S);
+        const float wr_m = (y - 1 >= 0) ? 0.25f : 0.0f, wr_p = (y + 1 < H) ? 0.25f : 0.0f;
+        const float rm[6] = { v.l[0], v.r[0].x, v.r[0].y, v.r[0].z, v.r[0].w, v.e[0] };
+        const float rc[6] = { v.l[1], v.r[1].x, v.r[1].y, v.r[1].z, v.r[1].w, v.e[1] };
+        const float rp[6] = { v.l[2], v.r[2].x, v.r[2].y, v.r[2].z, v.r[2].w, v.e[2] };
+        float *bb = blur + parity * BLUR_BUF + ph0 * M + c;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int xk = x + k;
+            const float wc_l = (xk - 1 >= 0) ? 0.25f : 0.0f, wc_r = (xk + 1 < W) ? 0.25f : 0.0f;
+            const float col_l = wr_m * rm[k] + 0.5f * rc[k] + wr_p * rp[k];
+            const float col_c = wr_m * rm[k + 1] + 0.5f * rc[k + 1] + wr_p * rp[k + 1];
+            const float col_r = wr_m * rm[k + 2] + 0.5f * rc[k + 2] + wr_p * rp[k + 2];
+            const float sum = wc_l * col_l + 0.5f * col_c + wc_r * col_r;
+            const float sumw = (wr_m + 0.5f + wr_p) * (wc_l + 0.5f + wc_r);
+            bb[k * M] = sum * __builtin_amdgcn_rcpf(sumw);
+        }
+    };
+
     // ---------------- loader threads: per-thread invariants ----------------
     constexpr int ML = (RW + kLoaderGroup - 1) / kLoaderGroup;
     constexpr int MBL = (2 * BW + kLoaderGroup - 1) / kLoaderGroup;
@@ -254,6 +311,7 @@ __global__ __launch_bounds__(NT) void k_atrous_lane(AtrousArgs a, LaneGeom gm)
     const int llane = is_loader ? (tid - NC) % kLoaderGroup : 0;
     Px lpx[ML];
     float lbv[MBL];
+    VB lvb;
     int l_xq[ML], l_lds[ML];
     int b_voff[MBL], b_lds[MBL];      // b_voff < 0: element does not exist or its column is outside the image
     bool b_d[MBL];
@@ -263,18 +321,20 @@ __global__ __launch_bounds__(NT) void k_atrous_lane(AtrousArgs a, LaneGeom gm)
 #pragma unroll
             for (int m = 0; m < ML; m++) {
                 const int xi = min(llane + m * kLoaderGroup, RW - 1);
-                const int xs = x0 - 2 * S + xi;
+                const int xs = xs_of(xi);
                 l_xq[m] = min(max(xs, 0), W - 1);
                 l_lds[m] = rec_of(xi) | ((xs >= 0 && xs < W) ? 0 : 0x40000000);
             }
+            if constexpr (!CHUNKED) {
 #pragma unroll
-            for (int m = 0; m < MBL; m++) {
-                const int e = llane + m * kLoaderGroup;
-                const int d = e / BW, xb = e - d * BW;
-                const int xs = x0 - 1 + xb;
-                b_d[m] = (d != 0);
-                b_lds[m] = (e < 2 * BW) ? (d * BLUR_ROW + bel_of(xb)) : -1;
-                b_voff[m] = (e < 2 * BW && xs >= 0 && xs < W) ? (int)((unsigned)xs * vxs) : -1;
+                for (int m = 0; m < MBL; m++) {
+                    const int e = llane + m * kLoaderGroup;
+                    const int d = e / BW, xb = e - d * BW;
+                    const int xs = x0 - 1 + xb;
+                    b_d[m] = (d != 0);
+                    b_lds[m] = (e < 2 * BW) ? (d * BLUR_ROW + bel_of(xb)) : -1;
+                    b_voff[m] = (e < 2 * BW && xs >= 0 && xs < W) ? (int)((unsigned)xs * vxs) : -1;
+                }
             }
         }
     };
@@ -296,7 +356,9 @@ __global__ __launch_bounds__(NT) void k_atrous_lane(AtrousArgs a, LaneGeom gm)
                 lpx[m].nx = n[0]; lpx[m].ny = n[1]; lpx[m].nz = n[2];
                 lpx[m].px = p[0]; lpx[m].py = p[1]; lpx[m].pz = p[2];
             }
-            if (a.blur_variance) {
+            if constexpr (CHUNKED) {
+                if (a.blur_variance) vblur_load(lvb, bo, llane);
+            } else if (a.blur_variance) {
                 const int ym = phase + (bo << LOG2S) - 1, yp = ym + 2;
                 const unsigned rm = (unsigned)min(max(ym, 0), H - 1) * vys, rp = (unsigned)min(max(yp, 0), H - 1) * vys;
 #pragma unroll
@@ -309,7 +371,9 @@ __global__ __launch_bounds__(NT) void k_atrous_lane(AtrousArgs a, LaneGeom gm)
         const int bo = b0 + j;
         if (bo < b1) {
             rows_store(lpx);
-            if (a.blur_variance) {
+            if constexpr (CHUNKED) {
+                if (a.blur_variance) vblur_store(lvb, bo, j & 1, llane);
+            } else if (a.blur_variance) {
                 const int ym = phase + (bo << LOG2S) - 1, yp = ym + 2;
                 const bool okm = ym >= 0 && ym < H, okp = yp >= 0 && yp < H;
                 float *bb = blur + (j & 1) * BLUR_BUF;
@@ -343,10 +407,13 @@ __global__ __launch_bounds__(NT) void k_atrous_lane(AtrousArgs a, LaneGeom gm)
         rows_load(px, b0 - 2, 3, tid, NC);
         constexpr int NB = (2 * BW + NC - 1) / NC;
         float bv[NB];
-        blur_load(bv, b0, tid, NC);
+        VB vb0;
+        if constexpr (CHUNKED) { if (a.blur_variance) vblur_load(vb0, b0, tid); }
+        else blur_load(bv, b0, tid, NC);
         stamp_at(2);
         rows_store(px);
-        if (a.blur_variance) blur_store(bv, 0, tid, NC);
+        if constexpr (CHUNKED) { if (a.blur_variance) vblur_store(vb0, b0, 0, tid); }
+        else if (a.blur_variance) blur_store(bv, 0, tid, NC);
         __syncthreads();                // A
         stamp_at(1);
     }
@@ -358,10 +425,13 @@ __global__ __launch_bounds__(NT) void k_atrous_lane(AtrousArgs a, LaneGeom gm)
         rows_load(px, b0 - 2, 5, tid, NT);
         constexpr int NB = (2 * BW + NT - 1) / NT;
         float bv[NB];
-        blur_load(bv, b0, tid, NT);
+        VB vb0;
+        if constexpr (CHUNKED) { if (a.blur_variance) vblur_load(vb0, b0, tid); }
+        else blur_load(bv, b0, tid, NT);
         loader_invariants();
         rows_store(px);
-        if (a.blur_variance) blur_store(bv, 0, tid, NT);
+        if constexpr (CHUNKED) { if (a.blur_variance) vblur_store(vb0, b0, 0, tid); }
+        else if (a.blur_variance) blur_store(bv, 0, tid, NT);
     }
     __syncthreads();
     stamp_at(1);
@@ -389,8 +459,8 @@ __global__ __launch_bounds__(NT) void k_atrous_lane(AtrousArgs a, LaneGeom gm)
     const bool flip = (wv >= NWC / 2);              // stage order of this wave, see body()
     const int xph = wv / WPP;                       // x-phase of this wave
     const int mcol = (wv % WPP) * LOUT + lane;      // lattice column inside the phase, 0 .. M-1
-    const int xi = xph + S * mcol;                  // staged pixel column
-    const int x = x0 - 2 * S + xi;                  // image column
+    const int xi = xph + P * mcol;                  // staged pixel column
+    const int x = xs_of(xi);                        // image column
     const bool out_lane = (lane >= 2) && (lane < 2 + LOUT) && (x < W);
     // An SGPR or literal source makes a VOP3 occupy the VALU as long as a packed instruction does (tools/ubench6.hip: 3.0
     // cycles per SIMD against 1.7 with three waves, 4.5 against 2.5 with two): the two slopes and the five distinct values of
@@ -590,6 +660,15 @@ __global__ __launch_bounds__(NT) void k_atrous_lane(AtrousArgs a, LaneGeom gm)
         const v4f A = *reinterpret_cast<const v4f *>(rowc);
         const v4f B = *reinterpret_cast<const v4f *>(rowc + 16);
         const v4f C = *reinterpret_cast<const v4f *>(rowc + 32);
+        ColRow r0;
+        GeoRow g1;
+        float var;
+        if constexpr (CHUNKED) {
+            // the loader threads computed the blurred variance of this row from the variance plane (see vblur_store)
+            const float bvar = blur[(it & 1) * BLUR_BUF + xph * M + mcol];
+            if (flip) load_geo(g1, bo + 1); else load_col(r0, bo - 2);
+            var = a.blur_variance ? bvar : C.w;
+        } else {
         const float *bl = blur + (it & 1) * BLUR_BUF;
         const float m0 = bl[be_l], m1 = bl[be_c], m2 = bl[be_r];
         const float p0 = bl[BLUR_ROW + be_l], p1 = bl[BLUR_ROW + be_c], p2 = bl[BLUR_ROW + be_r];
@@ -597,10 +676,7 @@ __global__ __launch_bounds__(NT) void k_atrous_lane(AtrousArgs a, LaneGeom gm)
         // the 48-byte lane stride, a 4-byte read is 4-way conflicted (lanes 8 apart share a bank)
         const float c0v = reinterpret_cast<const v4f *>(ringrow + off_l - 12)->w;
         const float c2v = reinterpret_cast<const v4f *>(ringrow + off_r - 12)->w;
-        ColRow r0;
-        GeoRow g1;
         if (flip) load_geo(g1, bo + 1); else load_col(r0, bo - 2);       // the first tap row of this wave's stage order
-        float var;
         {   // centre variance: 3x3 gaussian with out-of-image taps dropped and renormalised (:102-118)
             const float wr_m = (y - 1 >= 0) ? 0.25f : 0.0f, wr_p = (y + 1 < H) ? 0.25f : 0.0f;
             const float wc_l = (x - 1 >= 0) ? 0.25f : 0.0f, wc_r = (x + 1 < W) ? 0.25f : 0.0f;
@@ -611,6 +687,7 @@ __global__ __launch_bounds__(NT) void k_atrous_lane(AtrousArgs a, LaneGeom gm)
             const float sumw = (wr_m + 0.5f + wr_p) * (wc_l + 0.5f + wc_r);
             const float blurred = sum * __builtin_amdgcn_rcpf(sumw);
             var = a.blur_variance ? blurred : C.w;
+        }
         }
         var = fmaxf(var, 0.0f);
         const float lp = B.z;
@@ -758,17 +835,20 @@ __global__ __launch_bounds__(NT) void k_atrous_lane(AtrousArgs a, LaneGeom gm)
     }
 }
 
-template <int LOG2S, bool HASVAR>
+template <int LOG2S, bool HASVAR, int LOG2P = LOG2S>
 hipError_t launch_lane_cfg(const AtrousArgs &a, hipStream_t s)
 {
-    constexpr int S = 1 << LOG2S, M = LOUT * (NWC / S) + 4, MP = (S == 4) ? M + 2 : ((M * 12 % 64 == 0) ? M + 1 : M), BM = (BW + S - 1) / S;
-    const size_t lds = (size_t)R * S * MP * PXB + (size_t)2 * 2 * S * BM * 4 + 16;
+    constexpr int S = 1 << LOG2S, P = 1 << LOG2P, M = LOUT * (NWC / P) + 4, MP = (P == 4) ? M + 2 : ((M * 12 % 64 == 0) ? M + 1 : M), BM = (BW + S - 1) / S;
+    constexpr int TXL = LOUT * (NWC / P);
+    const size_t lds = (size_t)R * P * MP * PXB + (size_t)2 * (P < S ? P * M : 2 * S * BM) * 4 + 16;
+    static_assert((size_t)R * P * MP * PXB + (size_t)2 * (P < S ? P * M : 2 * S * BM) * 4 + 16 <= 160 * 1024, "LDS budget");
     static SvgfLaunchCache cache;
     int dev_id = 0;
-    if (hipError_t e = cache.init(reinterpret_cast<const void *>(&k_atrous_lane<LOG2S, HASVAR>), (int)lds, &dev_id); e != hipSuccess) return e;
+    if (hipError_t e = cache.init(reinterpret_cast<const void *>(&k_atrous_lane<LOG2S, HASVAR, LOG2P>), (int)lds, &dev_id); e != hipSuccess) return e;
     const int n_cu = cache.n_cu[dev_id];
     LaneGeom gm;
-    gm.n_strips = (a.W + TXO - 1) / TXO;
+    // strips: TXO contiguous pixel columns (P == S), or (lattice-column strip, group of P phases) pairs (P < S)
+    gm.n_strips = (P == S) ? (a.W + TXO - 1) / TXO : (((a.W + S - 1) / S + TXL - 1) / TXL) * (S / P);
     const int nb_max = (a.H + S - 1) / S;
     // segment length: one workgroup per CU (LDS-bound); the busiest XCD sets the number of rounds (see the strip kernel)
     int best_L = nb_max;
@@ -797,7 +877,7 @@ hipError_t launch_lane_cfg(const AtrousArgs &a, hipStream_t s)
         gm.dbg = dbg_buf; gm.dbg_block = atoi(dbg_env);
     }
 #endif
-    hipLaunchKernelGGL((k_atrous_lane<LOG2S, HASVAR>), dim3(nblocks), dim3(NT), lds, s, a, gm);
+    hipLaunchKernelGGL((k_atrous_lane<LOG2S, HASVAR, LOG2P>), dim3(nblocks), dim3(NT), lds, s, a, gm);
 #ifdef SVGF_LANE_TIMELINE
     if (dbg_env) {
         static int skip = getenv("SVGF_LANE_DBG_SKIP") ? atoi(getenv("SVGF_LANE_DBG_SKIP")) : 0, prints = 0;
@@ -831,6 +911,10 @@ hipError_t launch_lane_cfg(const AtrousArgs &a, hipStream_t s)
 
 bool atrous_lane_supported(const AtrousArgs &a)
 {
+    if (a.step == 16 || a.step == 32) {            // chunked x-phases: the loaders blur the variance from the 4-byte plane
+        if ((long long)a.W * a.H * 16 >= (1LL << 32)) return false;
+        return a.var != nullptr || !a.blur_variance;
+    }
     if (a.step != 1 && a.step != 2 && a.step != 4 && a.step != 8) return false;   // step 1: SvgfParams::paper_steps
     if ((long long)a.W * a.H * 16 >= (1LL << 32)) return false;
     return true;
@@ -843,6 +927,8 @@ hipError_t launch_atrous_lane(const AtrousArgs &a, hipStream_t s)
     case 2: return a.dst ? launch_lane_cfg<1, true>(a, s) : launch_lane_cfg<1, false>(a, s);
     case 4: return a.dst ? launch_lane_cfg<2, true>(a, s) : launch_lane_cfg<2, false>(a, s);
     case 8: return a.dst ? launch_lane_cfg<3, true>(a, s) : launch_lane_cfg<3, false>(a, s);
+    case 16: return a.dst ? launch_lane_cfg<4, true, 2>(a, s) : launch_lane_cfg<4, false, 2>(a, s);
+    case 32: return a.dst ? launch_lane_cfg<5, true, 3>(a, s) : launch_lane_cfg<5, false, 3>(a, s);
     default: return hipErrorInvalidValue;
     }
 }
