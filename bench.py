@@ -334,7 +334,7 @@ def main():
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "traffic_measured_live": False, "traffic_provenance": traffic_note,
                          "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, profiles/pmc_traffic.json (FETCH x2 per MI355X_MICROARCH.md)",
-                         "kernel": "one a-trous level: k_atrous_lane (steps 2-8), k_atrous_strip (steps 16-32); mean over the 5 launches of a frame", "bytes_per_launch": ATROUS_BYTES_PER_PIXEL * W * H,
+                         "kernel": "one a-trous level: k_atrous_lane (steps 2-32 at 1920 / 3840 / 800 columns; k_atrous_strip where the library's width heuristic prefers it); mean over the a-trous launches of a frame", "bytes_per_launch": ATROUS_BYTES_PER_PIXEL * W * H,
                          "mean_launch_us": round(a_ms * 1e3, 2), "launches_timed": len(atrous_ms),
                          "note": ("timed-region launches include levels that run beside the next frame's temporal pass "
                                   "(cross-frame overlap, --overlap); 'isolated' is the same kernel with the GPU to itself") if (a.overlap and not a.no_overlap)

@@ -378,7 +378,7 @@ struct KernelTimer {   // brackets one launch with an event pair when profiling 
 
 // ---- the frame ------------------------------------------------------------------------------------------------
 
-// Auto selection between the two fast a-trous kernels for steps 2-8: the lane-marching kernel works on 480-column strips,
+// Auto selection between the two fast a-trous kernels for steps 2-32: the lane-marching kernel works on 480-column strips,
 // the strip kernel on 256-column strips; the lane kernel is ~5 % faster per computed column, so it is chosen unless its
 // strips would leave noticeably more columns outside the image (1920, 3840, 800: lane; 1280, 2560, 1000: strip).
 static bool lane_pays(int W, int step)
@@ -568,7 +568,7 @@ static int denoise_frame(svgf_ctx *c, void *out_rgb_dev, const void *in_rgb_dev,
             }
             if (dst >= 0) { if (a.var_dst) c->vp_valid |= 1u << dst; else c->vp_valid &= ~(1u << dst); }
             switch (which) {
-            case K_LANE:    LAUNCH(SVGF_KERNEL_ATROUS, launch_atrous_lane(a, s)); break;     // steps 2, 4, 8: symmetric terms evaluated once
+            case K_LANE:    LAUNCH(SVGF_KERNEL_ATROUS, launch_atrous_lane(a, s)); break;     // steps 2 .. 32: symmetric terms evaluated once
             case K_STRIP:   LAUNCH(SVGF_KERNEL_ATROUS, launch_atrous_strip(a, s)); break;
             case K_LATTICE: LAUNCH(SVGF_KERNEL_ATROUS, launch_atrous_lattice(a, s)); break;
             default:        LAUNCH(SVGF_KERNEL_ATROUS, launch_atrous_gather(a, s)); break;

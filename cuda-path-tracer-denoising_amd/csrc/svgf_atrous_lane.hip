@@ -1,4 +1,4 @@
-// svgf_atrous_lane.hip — a-trous level with the symmetric part of every tap evaluated ONCE, for S = 2, 4, 8 (gfx950).
+// svgf_atrous_lane.hip — a-trous level with the symmetric part of every tap evaluated ONCE, for S = 2 .. 32 (gfx950).
 //
 // Same result as svgf_atrous_strip.hip (one level of reference ATrousFilter, src/denoise.cu:77-170, snapshot variance)
 // and the same staging machinery (LDS ring filled by loader waves, one barrier per iteration).  What changes is who
@@ -20,8 +20,8 @@
 // the outermost two lanes on either side of a wave are halo lanes (their shifted-in terms are garbage, they store
 // nothing): a wave produces 60 columns, a workgroup 8 waves x 60 x ... = 480 contiguous pixel columns.
 //     S = 2: 4 waves per x-phase     S = 4: 2 waves per x-phase     S = 8: 1 wave per x-phase
-// S >= 16 would need several phases inside one wave (28 or 12 useful lanes out of 32 / 16): those levels stay on the
-// strip kernel.
+// S = 16, 32: a workgroup holds 4 (8) ADJACENT x-phases only ("chunks", template parameter LOG2P), two (one) waves each;
+// see the comment in front of the kernel.
 //
 // LDS: ring 6 rows (b-2 .. b+2 live, b+3 incoming) x (480 + 4S) pixels x 48 B = 140.5 .. 147.5 KB, + pre-blur rows.
 #include "svgf_kernels.h"
@@ -860,6 +860,7 @@ hipError_t launch_lane_cfg(const AtrousArgs &a, hipStream_t s)
         const long cost = rounds * (L + 6);
         if (best_cost < 0 || cost <= best_cost) { best_cost = cost; best_L = L; }
     }
+    if (const char *e = getenv("SVGF_LANE_SEGROWS")) { int v = atoi(e); if (v > 0) best_L = v; }      // tuning only (tools/experiments/exp_small_frames.sh)
     gm.seg_rows = best_L;
     gm.n_segs = (nb_max + best_L - 1) / best_L;
     gm.n_groups = S * gm.n_segs;

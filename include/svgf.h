@@ -79,12 +79,14 @@ typedef struct SvgfParams {
     int   addcolor;           /* ui_addcolor         (0)    */
     int   right_view_option;  /* ui_right_view_option (0): 0 image, 1 history length, 2 variance */
     /* --- extensions; 0 == reference behaviour --- */
-    int   kernel_variant;     /* 0 auto (lane-marching kernel for steps 2-8, LDS strip kernel for steps 16-32, lattice
-                                 sub-image kernel for steps >= 64, gather where none applies), 1 strict gather kernel,
+    int   kernel_variant;     /* 0 auto (lane-marching kernel for steps 2-32 where its strips fit the image width — 1920,
+                                 3840, 800 columns ... — and, at steps 16-32, the source level left a variance plane; LDS
+                                 strip kernel otherwise; lattice sub-image kernel for steps >= 64; gather where none
+                                 applies), 1 strict gather kernel,
                                  2 LDS strip kernel for every step 2-32 (error if a step is unsupported, raised before
                                  anything is enqueued), 3 retired (was an experimental shared-weight kernel, now under
-                                 tools/experiments/; SVGF_ERR_INVALID_ARG), 4 lane-marching kernel for steps 2-8 + strip +
-                                 lattice whatever the image width */
+                                 tools/experiments/; SVGF_ERR_INVALID_ARG), 4 lane-marching kernel wherever it is supported (steps
+                                 2-32) whatever the image width, strip / lattice for the rest */
     int   inputs_ready;       /* 1: in_rgb/gbuffer are complete when svgf_denoise is CALLED (no producer still pending on
                                  `stream`).  Lets the temporal pass of this frame run on an internal stream concurrently
                                  with the previous frame's trailing a-trous levels.  0: everything is ordered on `stream`. */

@@ -23,11 +23,12 @@ sys.path.insert(0, ROOT)
 import bench  # noqa: E402  (kernel_sources_sha16: the fingerprint bench.py checks before it reports this record)
 d["kernel_sources_sha16"] = bench.kernel_sources_sha16()
 d["source_file"] = os.path.basename(sys.argv[1]) if len(sys.argv) > 1 else ""
-d["why_above_algorithmic"] = ("4 halo rows per 17-row segment (x1.24 on the 40 B/px read) and 2*S halo columns per strip; +4 B/px written by the levels "
-                              "that feed a step-16/32 level its 4-byte variance plane (which saves those levels ~24 B/px of 4-B gathers from 16-B texels)")
-d["_comment"] = ("HBM-side traffic of the a-trous kernels (default path: k_atrous_lane for steps 2-8, k_atrous_strip for 16-32) from rocprofv3 "
+d["why_above_algorithmic"] = ("4 halo rows per 17-row segment (x1.24 on the 40 B/px read) and 2 halo lattice columns either side of a strip; +4 B/px written by "
+                              "the levels that feed a step-16/32 level its 4-byte variance plane, and 8-12 B/px read from it there (three rows, fetched by the two "
+                              "or three XCDs that hold neighbouring y-phases) instead of ~24 B/px of 4-byte gathers from 16-byte texels")
+d["_comment"] = ("HBM-side traffic of the a-trous kernels (default path at 1920 columns: k_atrous_lane on all five levels) from rocprofv3 "
                  "PMC, collected as MI355X_MICROARCH.md prescribes: FETCH_SIZE and WRITE_SIZE in separate --pmc passes "
-                 "(profiles/r02_pmc_hbm.txt), KiB units, FETCH_SIZE doubled (gfx950 tallies 128-B read requests at 64 B). "
+                 "(profiles/r03_pmc_hbm.txt), KiB units, FETCH_SIZE doubled (gfx950 tallies 128-B read requests at 64 B). "
                  "Bytes per pixel per launch, 1920x1080.  Reported by bench.py only while kernel_sources_sha16 matches the sources.")
 json.dump(d, open(p, "w"), indent=2)
 print(json.dumps(lv), d["mean_bytes_per_pixel_per_launch"], d["mean_bytes_per_launch"])
