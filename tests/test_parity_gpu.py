@@ -191,6 +191,35 @@ def test_lattice_kernel_keeps_the_nan_semantics(pkg, orc):
     assert relerr(np.where(both_nan, 0, got), np.where(both_nan, 0, ref)).max() <= TOL_STRIP * 4
 
 
+@pytest.mark.parametrize("size,variant", [((1920, 70), 0), ((300, 200), 4), ((123, 77), 4), ((3840, 48), 0)])
+def test_lane_kernel_at_steps_16_and_32_nan_texels_and_options(pkg, orc, size, variant):
+    """Steps 16 / 32 on the lane-marching kernel (chunked x-phases, variance pre-blur computed by the loader threads): widths
+    where the automatic choice takes it (1920, 3840) and small images with kernel_variant 4; non-finite normal / position texels
+    (the `careful` path), variance blur off, re-modulation on the last level, the history fed by level 4 / 5, paper step sizes
+    (step 16 as the LAST level: the variant without variance accumulators)."""
+    W, H = size
+    o = orc.Oracle(pkg, W, H, threads=16)
+    d = pkg.Denoiser(W, H, 0)
+    cfgs = [dict(temporal_enable=1, history_level=1, blur_variance=1),
+            dict(temporal_enable=1, history_level=5, blur_variance=0, sepcolor=1, addcolor=1),
+            dict(temporal_enable=1, history_level=4, blur_variance=1, paper_steps=1),
+            dict(temporal_enable=0, history_level=0, blur_variance=1)]
+    for f, kw in enumerate(cfgs):
+        p = pkg.reference_defaults().set(spatial_enable=1, atrous_nlevel=5, kernel_variant=variant, **kw)
+        c, g, cam = pkg.synth.render_frame(W, H, f, seed=53, moving=True)
+        g = g.copy()
+        if f >= 1:
+            g["position"][H // 3, W // 2] = np.nan
+            g["normal"][H // 2, min(20, W - 1), 1] = np.inf
+        ref = o.denoise(c, g, cam, p)
+        got = d.denoise_host(c, g, cam, p)
+        assert np.array_equal(np.isnan(got), np.isnan(ref)), f"{W}x{H} frame {f}: NaN pattern"
+        both = np.isnan(got) & np.isnan(ref)
+        e = relerr(np.where(both, 0, got), np.where(both, 0, ref))
+        assert e.max() <= TOL_STRIP * 2, f"{W}x{H} variant {variant} frame {f} {kw}: {e.max():.3e}"
+    d.free(); o.free()
+
+
 def test_4k_size_independent_properties(pkg):
     """BASELINE config 4 size (3840x2160): properties that need no CPU oracle run."""
     import torch
