@@ -36,6 +36,15 @@
 #ifndef SVGF_LANE_SPLIT_PROLOGUE
 #define SVGF_LANE_SPLIT_PROLOGUE 1
 #endif
+#ifndef SVGF_LANE_PRIO
+// progress-based wave priorities: stage order A (start, after 1/4, after 2/3 of the row), stage order B (start, 1/3, 2/3, 3/4).
+// Order B keeps the higher priority for longer: its waves are the ones that reach the barrier last (profiles/r03_ab_lane_prio.log:
+// 3,2,1 / 3,2,1,0 -> 3,2,1 / 3,3,2,1 is -1.5 % per level; no priorities at all +6 %)
+#define SVGF_LANE_PRIO 3, 2, 1, 3, 3, 2, 1
+#endif
+#ifndef SVGF_LANE_LOADER_PRIO
+#define SVGF_LANE_LOADER_PRIO 2
+#endif
 #ifndef SVGF_LANE_G1
 #define SVGF_LANE_G1 1      // first forward row's geometry read one row ahead (1) or not (0)
 #endif
@@ -439,7 +448,7 @@ __global__ __launch_bounds__(NT) void k_atrous_lane(AtrousArgs a, LaneGeom gm)
 
     if (is_loader) {
         // ================================ loader waves (as in the strip kernel) ================================
-        __builtin_amdgcn_s_setprio(2);
+        __builtin_amdgcn_s_setprio(SVGF_LANE_LOADER_PRIO);
         int it = 0;
         for (int bo = b0; bo < b1; bo++, it++, dbg_it++) {
             stamp(0);
@@ -653,7 +662,9 @@ __global__ __launch_bounds__(NT) void k_atrous_lane(AtrousArgs a, LaneGeom gm)
     // plain 24-tap loop that keeps the reference's min(1, exp(-NaN)) == 1 and shares nothing.
     auto body = [&](int bo, int it, bool careful) {
         stamp(0);
-        __builtin_amdgcn_s_setprio(3);
+        constexpr int PR[7] = { SVGF_LANE_PRIO };
+        if constexpr (PR[0] == PR[3]) __builtin_amdgcn_s_setprio(PR[0]);
+        else { if (flip) __builtin_amdgcn_s_setprio(PR[3]); else __builtin_amdgcn_s_setprio(PR[0]); }
         const int y = phase + (bo << LOG2S);
         const char *rowc = colbase + slot_of(bo) * ROWB + 2 * PXB;
         const char *ringrow = smem + slot_of(bo) * ROWB;
@@ -760,7 +771,7 @@ __global__ __launch_bounds__(NT) void k_atrous_lane(AtrousArgs a, LaneGeom gm)
             load_own(r2, bo);
             row_fence(acc);
             do_col(acc, r1, pF1, lp, kl);
-            __builtin_amdgcn_s_setprio(2);                  // ~1/4 of the row's work done
+            __builtin_amdgcn_s_setprio(PR[1]);              // ~1/4 of the row's work done
             load_geo(g1, bo + 1);
             row_fence(acc);
             stamp(2);
@@ -769,7 +780,7 @@ __global__ __launch_bounds__(NT) void k_atrous_lane(AtrousArgs a, LaneGeom gm)
             row_fence(acc);
             // forward rows: evaluate, use, and keep for the partners
             do_geo(acc, g1, bo + 1, std::integral_constant<int, 1>{}, F1, c0, c1, c2, lp, kl, nullptr, 0);
-            __builtin_amdgcn_s_setprio(1);                  // ~2/3
+            __builtin_amdgcn_s_setprio(PR[2]);              // ~2/3
             row_fence(acc);
             GeoRow g2;
             load_geo(g2, bo + 2);
@@ -780,19 +791,19 @@ __global__ __launch_bounds__(NT) void k_atrous_lane(AtrousArgs a, LaneGeom gm)
             //      rows.  The forward rows are VALU-heavy, the backward rows LDS-heavy: with the two waves of a SIMD in
             //      opposite orders the two kinds of work overlap instead of queueing up behind the same pipe. ----
             do_geo(acc, g1, bo + 1, std::integral_constant<int, 1>{}, F1, c0, c1, c2, lp, kl, nullptr, 0);
-            __builtin_amdgcn_s_setprio(2);                  // ~1/3
+            __builtin_amdgcn_s_setprio(PR[4]);              // ~1/3
             row_fence(acc);
             GeoRow g2;
             load_geo(g2, bo + 2);
             do_geo(acc, g2, bo + 2, std::integral_constant<int, 2>{}, F2, c0, c1, c2, lp, kl, nullptr, 0);
-            __builtin_amdgcn_s_setprio(1);                  // ~2/3
+            __builtin_amdgcn_s_setprio(PR[5]);              // ~2/3
             OwnRow r2;
             load_own(r2, bo);
             row_fence(acc);
             stamp(2);
             load_col(r0, bo - 2);
             do_own(r2);
-            __builtin_amdgcn_s_setprio(0);                  // ~3/4
+            __builtin_amdgcn_s_setprio(PR[6]);              // ~3/4
             stamp(3);
             row_fence(acc);
             ColRow r1;
