@@ -660,17 +660,34 @@ __global__ __launch_bounds__(NT) void k_atrous_lane(AtrousArgs a, LaneGeom gm)
     // One iteration = one output row.  Once a non-finite normal / position has been staged (rare; the flag only ever
     // goes from 0 to 1, and is set before the row that needs it becomes anybody's partner) the workgroup switches to a
     // plain 24-tap loop that keeps the reference's min(1, exp(-NaN)) == 1 and shares nothing.
-    auto body = [&](int bo, int it, bool careful) {
+    // The centre's geometry and the variance of its two row neighbours are in the ring long before the row becomes the output
+    // row: the variant without variance accumulators (150 / 138 VGPRs, room for 10 more) reads them at the END of the previous
+    // iteration, in front of its output stage, so that the LDS round trip is over when the barrier opens — after the barrier
+    // all eight waves ask at once, with nothing else to issue (-0.7 .. -1.3 us on that level).  At 164 VGPRs the carried
+    // registers cost the other variants what the prefetch brings (profiles/r03_ab_lane_centre_prefetch.log): they read at the top.
+    constexpr bool PREFETCH_CENTRE = !HASVAR;
+    struct Centre { v4f A, B; float c0v, c2v; };
+    auto prefetch_centre = [&](Centre &cn, int bo) {
+        const char *rowc = colbase + slot_of(bo) * ROWB + 2 * PXB;
+        cn.A = *reinterpret_cast<const v4f *>(rowc);
+        cn.B = *reinterpret_cast<const v4f *>(rowc + 16);
+        if constexpr (!CHUNKED) {
+            // variance of the row neighbours x-1, x+1 (other x-phases): read as their whole C slot — a b128 is conflict-free at
+            // the 48-byte lane stride, a 4-byte read is 4-way conflicted (lanes 8 apart share a bank)
+            const char *ringrow = smem + slot_of(bo) * ROWB;
+            cn.c0v = reinterpret_cast<const v4f *>(ringrow + off_l - 12)->w;
+            cn.c2v = reinterpret_cast<const v4f *>(ringrow + off_r - 12)->w;
+        } else { cn.c0v = 0.0f; cn.c2v = 0.0f; }
+    };
+    auto body = [&](int bo, int it, bool careful, Centre &cen) {
         stamp(0);
         constexpr int PR[7] = { SVGF_LANE_PRIO };
         if constexpr (PR[0] == PR[3]) __builtin_amdgcn_s_setprio(PR[0]);
         else { if (flip) __builtin_amdgcn_s_setprio(PR[3]); else __builtin_amdgcn_s_setprio(PR[0]); }
         const int y = phase + (bo << LOG2S);
-        const char *rowc = colbase + slot_of(bo) * ROWB + 2 * PXB;
-        const char *ringrow = smem + slot_of(bo) * ROWB;
-        const v4f A = *reinterpret_cast<const v4f *>(rowc);
-        const v4f B = *reinterpret_cast<const v4f *>(rowc + 16);
-        const v4f C = *reinterpret_cast<const v4f *>(rowc + 32);
+        if constexpr (!PREFETCH_CENTRE) prefetch_centre(cen, bo);
+        const v4f A = cen.A, B = cen.B;
+        const v4f C = *reinterpret_cast<const v4f *>(colbase + slot_of(bo) * ROWB + 2 * PXB + 32);
         ColRow r0;
         GeoRow g1;
         float var;
@@ -683,10 +700,7 @@ __global__ __launch_bounds__(NT) void k_atrous_lane(AtrousArgs a, LaneGeom gm)
         const float *bl = blur + (it & 1) * BLUR_BUF;
         const float m0 = bl[be_l], m1 = bl[be_c], m2 = bl[be_r];
         const float p0 = bl[BLUR_ROW + be_l], p1 = bl[BLUR_ROW + be_c], p2 = bl[BLUR_ROW + be_r];
-        // variance of the row neighbours x-1, x+1 (other x-phases): read as their whole C slot — a b128 is conflict-free at
-        // the 48-byte lane stride, a 4-byte read is 4-way conflicted (lanes 8 apart share a bank)
-        const float c0v = reinterpret_cast<const v4f *>(ringrow + off_l - 12)->w;
-        const float c2v = reinterpret_cast<const v4f *>(ringrow + off_r - 12)->w;
+        const float c0v = cen.c0v, c2v = cen.c2v;
         if (flip) load_geo(g1, bo + 1); else load_col(r0, bo - 2);       // the first tap row of this wave's stage order
         {   // centre variance: 3x3 gaussian with out-of-image taps dropped and renormalised (:102-118)
             const float wr_m = (y - 1 >= 0) ? 0.25f : 0.0f, wr_p = (y + 1 < H) ? 0.25f : 0.0f;
@@ -817,6 +831,8 @@ __global__ __launch_bounds__(NT) void k_atrous_lane(AtrousArgs a, LaneGeom gm)
         }
 
         stamp(4);
+        Centre nxt;
+        if constexpr (PREFETCH_CENTRE) prefetch_centre(nxt, bo + 1);          // row bo+1 has been in the ring since iteration it-2
         if (out_lane) {
             const float r0 = acc.rg.x, r1 = acc.rg.y, r2 = acc.bv.x, vsum = acc.bv.y, wsum = acc.ww.x, w2sum = acc.ww.y;
             float o0, o1, o2, ov;
@@ -833,11 +849,14 @@ __global__ __launch_bounds__(NT) void k_atrous_lane(AtrousArgs a, LaneGeom gm)
             if (a.var_dst) a.var_dst[(unsigned)(y + 1) * (unsigned)(W + 2) + (unsigned)(x + 1)] = ov;
             if (a.out_rgb) { float *o = a.out_rgb + 3u * p; o[0] = o0; o[1] = o1; o[2] = o2; }
         }
+        if constexpr (PREFETCH_CENTRE) cen = nxt;
     };
 
     int it = 0;
+    Centre cen;
+    if constexpr (PREFETCH_CENTRE) prefetch_centre(cen, b0);
     for (int bo = b0; bo < b1; bo++, it++) {
-        body(bo, it, *nan_seen != 0);
+        body(bo, it, *nan_seen != 0, cen);
         stamp(5);
         __syncthreads();
         stamp(6);
