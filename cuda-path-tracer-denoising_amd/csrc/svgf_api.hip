@@ -24,6 +24,7 @@ struct svgf_ctx {
     float *vp[4];          // zero-margined (W+2) x (H+2) copies of cv[k].w for the pre-blur of the per-wave a-trous kernel
     unsigned vp_valid;     // bit k: vp[k] holds the variance of cv[k]
     int use_vplane;        // 0 only for A/B measurements (environment SVGF_NO_VARIANCE_PLANE at svgf_create)
+    int n_cu;              // compute units of the context's device (launch-geometry cost model of the kernel choice)
     float *nrm[2];
     int *gid[2];
     float *pos[2];
@@ -189,6 +190,7 @@ extern "C" int svgf_create(int device, int width, int height, svgf_ctx **out)
     c->device = device; c->W = width; c->H = height; c->n = (size_t)width * height;
     for (int k = 0; k < 16; k++) c->view_prev[k] = (k % 5 == 0) ? 1.0f : 0.0f;
     c->use_vplane = getenv("SVGF_NO_VARIANCE_PLANE") ? 0 : 1;
+    if (hipDeviceGetAttribute(&c->n_cu, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || c->n_cu < 8) c->n_cu = 256;
     bool ok = true;
     // three colour planes serve the ordered path (history, source, destination); the fourth one, the side stream and its
     // events belong to the cross-frame overlap and are created when a frame first asks for it (ensure_overlap_resources)
@@ -378,20 +380,16 @@ struct KernelTimer {   // brackets one launch with an event pair when profiling 
 
 // ---- the frame ------------------------------------------------------------------------------------------------
 
-// Auto selection between the two fast a-trous kernels for steps 2-32: the lane-marching kernel works on 480-column strips,
-// the strip kernel on 256-column strips; the lane kernel is ~5 % faster per computed column, so it is chosen unless its
-// strips would leave noticeably more columns outside the image (1920, 3840, 800: lane; 1280, 2560, 1000: strip).
-static bool lane_pays(int W, int step)
+// Auto selection between the two fast a-trous kernels for steps 2-32.  The lane-marching kernel works on 480-column strips (at
+// steps 16 / 32: 120 / 60 lattice columns of 4 / 8 x-phases), the strip kernel on 256-column strips; both cut the image into
+// (strip, y-phase, segment) workgroups that run in rounds of one per CU, and both know what their launch will cost:
+// rounds x (segment rows + fixed rows) x the time of a row (1.86 us lane, 1.16 us strip: 42.7 against 48.8 us at 1920x1080).
+// The cheaper one runs.  Measured against that model at nine sizes (profiles/r03_exp_widths*.log): within 5 %, same choice as
+// the stopwatch everywhere — lane at 1920, 3840, 1600, 3440, 800 (steps 2-8), 2560 and 1280 (steps 2-8, 32); strip at 1024,
+// 2048, and at steps 16 of 800 / 1280 / 2560.
+static bool lane_pays(const AtrousArgs &a, int n_cu)
 {
-    const double util_strip = (double)W / (double)(((W + 255) / 256) * 256);
-    if (step >= 16) {
-        // chunked x-phases: a workgroup outputs 120 (step 16) or 60 (step 32) lattice columns of each of its 4 (8) phases
-        const int cols = (W + step - 1) / step, txl = (step == 16) ? 120 : 60;
-        const double util_lane = (double)cols / (double)(((cols + txl - 1) / txl) * txl);
-        return util_lane * 1.05 >= util_strip;
-    }
-    const double util_lane = (double)W / (double)(((W + 479) / 480) * 480);
-    return util_lane * 1.05 >= util_strip;
+    return atrous_lane_estimate_us(a, n_cu) <= atrous_strip_estimate_us(a, n_cu);
 }
 
 // gbuffer_dev == nullptr: the planar path (svgf_denoise_planar) — the current-frame planes nrm/pos/gid[1 - gcur] (and `albedo`)
@@ -551,7 +549,7 @@ static int denoise_frame(svgf_ctx *c, void *out_rgb_dev, const void *in_rgb_dev,
                 lattice = !strip && p->kernel_variant != 2 && atrous_lattice_supported(a);     // steps 64, 128, ...
             }
             enum { K_LANE, K_STRIP, K_LATTICE, K_GATHER } which;
-            if (strip && atrous_lane_supported(a) && (p->kernel_variant == 4 || (p->kernel_variant == 0 && lane_pays(c->W, a.step)))) which = K_LANE;
+            if (strip && atrous_lane_supported(a) && (p->kernel_variant == 4 || (p->kernel_variant == 0 && lane_pays(a, c->n_cu)))) which = K_LANE;
             else if (strip) which = K_STRIP;
             else if (lattice) which = K_LATTICE;
             else which = K_GATHER;

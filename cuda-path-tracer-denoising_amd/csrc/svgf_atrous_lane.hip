@@ -20,7 +20,7 @@
 // the outermost two lanes on either side of a wave are halo lanes (their shifted-in terms are garbage, they store
 // nothing): a wave produces 60 columns, a workgroup 8 waves x 60 x ... = 480 contiguous pixel columns.
 //     S = 2: 4 waves per x-phase     S = 4: 2 waves per x-phase     S = 8: 1 wave per x-phase
-// S = 16, 32: a workgroup holds 4 (8) ADJACENT x-phases only ("chunks", template parameter LOG2P), two (one) waves each;
+// S = 16, 32: a workgroup holds 8 ADJACENT x-phases only ("chunks", template parameter LOG2P), one wave each;
 // see the comment in front of the kernel.
 //
 // LDS: ring 6 rows (b-2 .. b+2 live, b+3 incoming) x (480 + 4S) pixels x 48 B = 140.5 .. 147.5 KB, + pre-blur rows.
@@ -101,9 +101,11 @@ __device__ __forceinline__ float lane_from(float v)
     return __builtin_bit_cast(float, x);
 }
 
-// LOG2P < LOG2S (steps 16, 32): a workgroup's 8 waves hold only P = 4 (8) of the S x-phases — "chunks" of P adjacent pixels
-// every S pixels — and all the lattice columns of those phases that a wave can hold: at 1920 pixels 120 (60) columns per
-// phase = exactly two (one) waves of 60.  Everything downstream of the staging is unchanged (a wave is still 64 consecutive
+// LOG2P < LOG2S (steps 16, 32): a workgroup's 8 waves hold only P = 8 of the S x-phases — "chunks" of 8 adjacent pixels (one
+// 128-byte line of colour) every S pixels — and 60 lattice columns of each: at 1920 pixels a phase has 120 (60) lattice columns,
+// so two (one) lattice strips x two (four) phase groups = four workgroups tile a row exactly.  (P = 4 with two waves per phase
+// also tiles 1920 at step 16 and was the first version: same speed at 1080p, 6-9 % slower at 3000-3840 columns, where its
+// 64-byte pieces of colour rows cost more than they carry; profiles/r03_exp_s16_p8.log.)  Everything downstream of the staging is unchanged (a wave is still 64 consecutive
 // lattice columns of one x-phase); what changes is (a) the pixel a staged column stands for, (b) the 3x3 variance pre-blur:
 // a centre's x-1 / x+1 neighbours lie in phases the workgroup may not stage, so for P < S the LOADER threads compute the
 // blurred variance of every pixel of the incoming output row from the producer's 4-byte variance plane (three rows x
@@ -865,11 +867,35 @@ __global__ __launch_bounds__(NT) void k_atrous_lane(AtrousArgs a, LaneGeom gm)
     }
 }
 
+// strips: TXO contiguous pixel columns (one x-phase per wave group), or (lattice-column strip, group of P phases) pairs (chunked)
+int lane_strip_count(int W, int S)
+{
+    if (S <= 8) return (W + TXO - 1) / TXO;
+    const int P = 8, txl = LOUT * (NWC / P);      // steps 16, 32: chunks of 8 x-phases, one wave of 60 lattice columns each
+    return (((W + S - 1) / S + txl - 1) / txl) * (S / P);
+}
+
+// segment length: one workgroup per CU (LDS-bound); the busiest XCD sets the number of rounds (see the strip kernel).  Returns
+// the minimum of rounds * (L + 6) in lattice rows and the segment length that reaches it.
+long lane_segment_search(int n_strips, int S, int nb_max, int n_cu, int *best_L_out)
+{
+    int best_L = nb_max;
+    long best_cost = -1;
+    for (int L = 4; L <= nb_max + 1; L++) {
+        const int segs_l = (nb_max + L - 1) / L;
+        const long blocks_xcd = (long)n_strips * ((S * segs_l + 7) / 8);
+        const long rounds = (blocks_xcd + n_cu / 8 - 1) / (n_cu / 8);
+        const long cost = rounds * (L + 6);
+        if (best_cost < 0 || cost <= best_cost) { best_cost = cost; best_L = L; }
+    }
+    *best_L_out = best_L;
+    return best_cost;
+}
+
 template <int LOG2S, bool HASVAR, int LOG2P = LOG2S>
 hipError_t launch_lane_cfg(const AtrousArgs &a, hipStream_t s)
 {
     constexpr int S = 1 << LOG2S, P = 1 << LOG2P, M = LOUT * (NWC / P) + 4, MP = (P == 4) ? M + 2 : ((M * 12 % 64 == 0) ? M + 1 : M), BM = (BW + S - 1) / S;
-    constexpr int TXL = LOUT * (NWC / P);
     const size_t lds = (size_t)R * P * MP * PXB + (size_t)2 * (P < S ? P * M : 2 * S * BM) * 4 + 16;
     static_assert((size_t)R * P * MP * PXB + (size_t)2 * (P < S ? P * M : 2 * S * BM) * 4 + 16 <= 160 * 1024, "LDS budget");
     static SvgfLaunchCache cache;
@@ -877,19 +903,11 @@ hipError_t launch_lane_cfg(const AtrousArgs &a, hipStream_t s)
     if (hipError_t e = cache.init(reinterpret_cast<const void *>(&k_atrous_lane<LOG2S, HASVAR, LOG2P>), (int)lds, &dev_id); e != hipSuccess) return e;
     const int n_cu = cache.n_cu[dev_id];
     LaneGeom gm;
-    // strips: TXO contiguous pixel columns (P == S), or (lattice-column strip, group of P phases) pairs (P < S)
-    gm.n_strips = (P == S) ? (a.W + TXO - 1) / TXO : (((a.W + S - 1) / S + TXL - 1) / TXL) * (S / P);
+    gm.n_strips = lane_strip_count(a.W, S);
+    static_assert(P == S || ((S == 16 || S == 32) && P == 8), "lane_strip_count knows these chunk sizes");
     const int nb_max = (a.H + S - 1) / S;
-    // segment length: one workgroup per CU (LDS-bound); the busiest XCD sets the number of rounds (see the strip kernel)
     int best_L = nb_max;
-    long best_cost = -1;
-    for (int L = 4; L <= nb_max + 1; L++) {
-        const int segs_l = (nb_max + L - 1) / L;
-        const long blocks_xcd = (long)gm.n_strips * ((S * segs_l + 7) / 8);
-        const long rounds = (blocks_xcd + n_cu / 8 - 1) / (n_cu / 8);
-        const long cost = rounds * (L + 6);
-        if (best_cost < 0 || cost <= best_cost) { best_cost = cost; best_L = L; }
-    }
+    (void)lane_segment_search(gm.n_strips, S, nb_max, n_cu, &best_L);
     if (const char *e = getenv("SVGF_LANE_SEGROWS")) { int v = atoi(e); if (v > 0) best_L = v; }      // tuning only (tools/experiments/exp_small_frames.sh)
     gm.seg_rows = best_L;
     gm.n_segs = (nb_max + best_L - 1) / best_L;
@@ -940,6 +958,15 @@ hipError_t launch_lane_cfg(const AtrousArgs &a, hipStream_t s)
 
 }  // namespace
 
+// Estimated duration of a level on this kernel: the launch geometry's cost in lattice rows x 1.86 us (1920x1080: one round of
+// 17 + 6 rows = 42.7 us; profiles/r03_exp_widths*.log: within 5 % at eight other sizes).  Used by the automatic kernel choice.
+double atrous_lane_estimate_us(const AtrousArgs &a, int n_cu)
+{
+    const int S = a.step;
+    int L = 0;
+    return 1.857 * (double)lane_segment_search(lane_strip_count(a.W, S), S, (a.H + S - 1) / S, n_cu, &L);
+}
+
 bool atrous_lane_supported(const AtrousArgs &a)
 {
     if (a.step == 16 || a.step == 32) {            // chunked x-phases: the loaders blur the variance from the 4-byte plane
@@ -958,7 +985,7 @@ hipError_t launch_atrous_lane(const AtrousArgs &a, hipStream_t s)
     case 2: return a.dst ? launch_lane_cfg<1, true>(a, s) : launch_lane_cfg<1, false>(a, s);
     case 4: return a.dst ? launch_lane_cfg<2, true>(a, s) : launch_lane_cfg<2, false>(a, s);
     case 8: return a.dst ? launch_lane_cfg<3, true>(a, s) : launch_lane_cfg<3, false>(a, s);
-    case 16: return a.dst ? launch_lane_cfg<4, true, 2>(a, s) : launch_lane_cfg<4, false, 2>(a, s);
+    case 16: return a.dst ? launch_lane_cfg<4, true, 3>(a, s) : launch_lane_cfg<4, false, 3>(a, s);
     case 32: return a.dst ? launch_lane_cfg<5, true, 3>(a, s) : launch_lane_cfg<5, false, 3>(a, s);
     default: return hipErrorInvalidValue;
     }

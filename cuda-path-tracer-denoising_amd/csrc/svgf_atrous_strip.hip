@@ -647,6 +647,27 @@ __global__ __launch_bounds__(TX * ROWS + loader_threads(TX, ROWS)) void k_atrous
     }
 }
 
+// Segment length: every (strip, phase, segment) is one workgroup and `capacity` of them run at a time, so the grid runs in
+// rounds of equal-length workgroups.  Returns the minimum of rounds * (L + fixed cost) — in lattice rows; the fixed cost being
+// the 4 halo rows + the exposed prologue latency — and the segment length L that reaches it.
+long strip_segment_search(int n_strips, int S, int nb_max, int ROWS, int capacity, int *best_L_out)
+{
+    int best_L = nb_max;
+    long best_cost = -1;
+    static const int fixed_rows = getenv("SVGF_STRIP_FIXED_ROWS") ? atoi(getenv("SVGF_STRIP_FIXED_ROWS")) : 8;   // tuning only
+    for (int L = ROWS * 4; L <= nb_max + ROWS; L++) {        // L need not be a multiple of ROWS: the last iteration idles rows
+        const int segs_l = (nb_max + L - 1) / L;
+        // (phase, segment) groups are dealt round-robin to the 8 XCDs (blockIdx % 8), all strips of a group to the same
+        // XCD: the busiest XCD, with ceil(groups / 8) groups, sets the number of rounds
+        const long blocks_xcd = (long)n_strips * ((S * segs_l + 7) / 8);
+        const long rounds = (blocks_xcd + capacity / 8 - 1) / (capacity / 8);
+        const long cost = rounds * ((L + ROWS - 1) / ROWS * ROWS + fixed_rows);
+        if (best_cost < 0 || cost <= best_cost) { best_cost = cost; best_L = L; }   // ties: fewer, longer workgroups
+    }
+    *best_L_out = best_L;
+    return best_cost;
+}
+
 template <int LOG2S, int TX, int ROWS, bool HASVAR>
 hipError_t launch_cfg(const AtrousArgs &a, hipStream_t s)
 {
@@ -668,17 +689,7 @@ hipError_t launch_cfg(const AtrousArgs &a, hipStream_t s)
     if (bpc < 1) bpc = 1;
     const int capacity = n_cu * bpc;
     int best_L = nb_max;
-    long best_cost = -1;
-    static const int fixed_rows = getenv("SVGF_STRIP_FIXED_ROWS") ? atoi(getenv("SVGF_STRIP_FIXED_ROWS")) : 8;   // tuning only
-    for (int L = ROWS * 4; L <= nb_max + ROWS; L++) {        // L need not be a multiple of ROWS: the last iteration idles rows
-        const int segs_l = (nb_max + L - 1) / L;
-        // (phase, segment) groups are dealt round-robin to the 8 XCDs (blockIdx % 8), all strips of a group to the same
-        // XCD: the busiest XCD, with ceil(groups / 8) groups, sets the number of rounds
-        const long blocks_xcd = (long)gm.n_strips * ((S * segs_l + 7) / 8);
-        const long rounds = (blocks_xcd + capacity / 8 - 1) / (capacity / 8);
-        const long cost = rounds * ((L + ROWS - 1) / ROWS * ROWS + fixed_rows);
-        if (best_cost < 0 || cost <= best_cost) { best_cost = cost; best_L = L; }   // ties: fewer, longer workgroups
-    }
+    (void)strip_segment_search(gm.n_strips, S, nb_max, ROWS, capacity, &best_L);
     if (const char *e = getenv("SVGF_STRIP_SEGROWS")) { int v = atoi(e); if (v > 0) best_L = v; }
     gm.seg_rows = best_L;
     gm.n_segs = (nb_max + best_L - 1) / best_L;
@@ -754,6 +765,24 @@ bool atrous_strip_supported(const AtrousArgs &a)
     if (a.step < 1 || a.step > 32 || (a.step & (a.step - 1))) return false;      // step 1: SvgfParams::paper_steps
     if ((long long)a.W * a.H * 16 >= (1LL << 32)) return false;   // 32-bit element offsets in the kernel
     return true;
+}
+
+// Estimated duration of a level on this kernel: the launch geometry's cost in lattice rows x 1.16 us (1920x1080: one round of
+// 34 + 8 rows = 48.8 us; profiles/r03_exp_widths*.log: within 5 % at eight other sizes).  Used by the automatic kernel choice.
+double atrous_strip_estimate_us(const AtrousArgs &a, int n_cu)
+{
+    int log2s = 0;
+    while ((1 << log2s) < a.step) log2s++;
+    int tx, rows;
+    pick(log2s, a.W, tx, rows);
+    const int S = 1 << log2s;
+    const size_t lds = (size_t)(4 + 2 * rows) * (tx + 4 * S) * 48 + (size_t)2 * rows * 2 * (tx + 2) * 4 + 16;
+    int bpc = (int)((160 * 1024) / lds);
+    const int threads = tx * rows + loader_threads(tx, rows);
+    if (bpc > 2048 / threads) bpc = 2048 / threads;
+    if (bpc < 1) bpc = 1;
+    int L = 0;
+    return 1.162 * (double)strip_segment_search((a.W + tx - 1) / tx, S, (a.H + S - 1) / S, rows, n_cu * bpc, &L);
 }
 
 #define STRIP_CASE(L, T, Rr) if (log2s == L && tx == T && rows == Rr) return a.dst ? launch_cfg<L, T, Rr, true>(a, s) : launch_cfg<L, T, Rr, false>(a, s);

@@ -98,8 +98,10 @@ hipError_t launch_prepare(const float *in_rgb, const float *gbuf, float4 *cv, fl
 hipError_t launch_atrous_gather(const AtrousArgs &a, hipStream_t s);   // strict one-thread-per-pixel gather kernel
 hipError_t launch_atrous_strip(const AtrousArgs &a, hipStream_t s);    // LDS strip-marching kernel (fast path)
 bool       atrous_strip_supported(const AtrousArgs &a);
-hipError_t launch_atrous_lane(const AtrousArgs &a, hipStream_t s);     // lane-marching kernel, symmetric terms shared by DPP (steps 2,4,8)
+double     atrous_strip_estimate_us(const AtrousArgs &a, int n_cu);   // launch-geometry cost model (automatic kernel choice)
+hipError_t launch_atrous_lane(const AtrousArgs &a, hipStream_t s);     // lane-marching kernel, symmetric terms shared by DPP (steps 1 .. 32)
 bool       atrous_lane_supported(const AtrousArgs &a);
+double     atrous_lane_estimate_us(const AtrousArgs &a, int n_cu);
 hipError_t launch_atrous_lattice(const AtrousArgs &a, hipStream_t s);  // lattice sub-images in LDS (steps >= 64)
 bool       atrous_lattice_supported(const AtrousArgs &a);
 // albedo * ialbedo of the last level's re-modulation (:166-168), from the AoS texel or from the planar path's plane
