@@ -79,10 +79,11 @@ typedef struct SvgfParams {
     int   addcolor;           /* ui_addcolor         (0)    */
     int   right_view_option;  /* ui_right_view_option (0): 0 image, 1 history length, 2 variance */
     /* --- extensions; 0 == reference behaviour --- */
-    int   kernel_variant;     /* 0 auto (lane-marching kernel for steps 2-32 where its strips fit the image width — 1920,
-                                 3840, 800 columns ... — and, at steps 16-32, the source level left a variance plane; LDS
-                                 strip kernel otherwise; lattice sub-image kernel for steps >= 64; gather where none
-                                 applies), 1 strict gather kernel,
+    int   kernel_variant;     /* 0 auto (steps 2-32: the cheaper of the lane-marching and the LDS strip kernel by their
+                                 launch-geometry cost model — lane at 1920, 3840, 1600, 3440 columns ..., strip at 1024,
+                                 2048 ...; the lane kernel at steps 16-32 also needs the variance plane the previous level
+                                 leaves; lattice sub-image kernel for steps >= 64; gather where none applies),
+                                 1 strict gather kernel,
                                  2 LDS strip kernel for every step 2-32 (error if a step is unsupported, raised before
                                  anything is enqueued), 3 retired (was an experimental shared-weight kernel, now under
                                  tools/experiments/; SVGF_ERR_INVALID_ARG), 4 lane-marching kernel wherever it is supported (steps
