@@ -540,6 +540,10 @@ __global__ __launch_bounds__(NT) void k_atrous_lane(AtrousArgs a, LaneGeom gm)
         }
     };
 
+#ifndef SVGF_LANE_LUM_B128_ALL
+#define SVGF_LANE_LUM_B128_ALL 1
+#endif
+    constexpr bool LUM_B128 = HASVAR || SVGF_LANE_LUM_B128_ALL;
     struct ColRow { v4f C[5]; float l[5]; };              // colour-only row: colour slot + luminance of the 5 taps
     struct GeoRow { v4f A[5], B[5]; };                    // forward row: geometry slots (the colour slot is read mid-row)
     struct OwnRow { v4f A[2], B[2], C[2], Cb[2]; float l[2]; };   // own row: +1, +2 full records; -1, -2 colour + luminance
@@ -549,9 +553,8 @@ __global__ __launch_bounds__(NT) void k_atrous_lane(AtrousArgs a, LaneGeom gm)
         for (int i = 0; i < 5; i++) {
             r.C[i] = *reinterpret_cast<const v4f *>(rowp + i * PXB + 32);
             // luminance: the whole B slot as a b128 (conflict-free at the 48-byte lane stride; an 8-byte read of {lum, pad}
-            // is 2-way conflicted: lanes 16 apart share banks).  The variant without variance accumulators sits at the
-            // 168-VGPR edge of three waves per SIMD and keeps the narrow read.
-            if constexpr (HASVAR) r.l[i] = reinterpret_cast<const v4f *>(rowp + i * PXB + 16)->z;
+            // is 2-way conflicted: lanes 16 apart share banks)
+            if constexpr (LUM_B128) r.l[i] = reinterpret_cast<const v4f *>(rowp + i * PXB + 16)->z;
             else r.l[i] = reinterpret_cast<const v2f *>(rowp + i * PXB + 24)->x;
         }
     };
@@ -571,7 +574,7 @@ __global__ __launch_bounds__(NT) void k_atrous_lane(AtrousArgs a, LaneGeom gm)
             r.B[k] = *reinterpret_cast<const v4f *>(rowp + (k + 3) * PXB + 16);
             r.C[k] = *reinterpret_cast<const v4f *>(rowp + (k + 3) * PXB + 32);
             r.Cb[k] = *reinterpret_cast<const v4f *>(rowp + (1 - k) * PXB + 32);
-            if constexpr (HASVAR) r.l[k] = reinterpret_cast<const v4f *>(rowp + (1 - k) * PXB + 16)->z;
+            if constexpr (LUM_B128) r.l[k] = reinterpret_cast<const v4f *>(rowp + (1 - k) * PXB + 16)->z;
             else r.l[k] = reinterpret_cast<const v2f *>(rowp + (1 - k) * PXB + 24)->x;
         }
     };
