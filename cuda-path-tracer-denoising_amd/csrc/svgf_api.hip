@@ -25,6 +25,7 @@ struct svgf_ctx {
     unsigned vp_valid;     // bit k: vp[k] holds the variance of cv[k]
     int use_vplane;        // 0 only for A/B measurements (environment SVGF_NO_VARIANCE_PLANE at svgf_create)
     int n_cu;              // compute units of the context's device (launch-geometry cost model of the kernel choice)
+    signed char lane_cheaper[8];   // per log2(step): -1 not evaluated yet, 1 the lane kernel's estimate is the lower one
     float *nrm[2];
     int *gid[2];
     float *pos[2];
@@ -191,6 +192,7 @@ extern "C" int svgf_create(int device, int width, int height, svgf_ctx **out)
     for (int k = 0; k < 16; k++) c->view_prev[k] = (k % 5 == 0) ? 1.0f : 0.0f;
     c->use_vplane = getenv("SVGF_NO_VARIANCE_PLANE") ? 0 : 1;
     if (hipDeviceGetAttribute(&c->n_cu, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || c->n_cu < 8) c->n_cu = 256;
+    memset(c->lane_cheaper, -1, sizeof(c->lane_cheaper));
     bool ok = true;
     // three colour planes serve the ordered path (history, source, destination); the fourth one, the side stream and its
     // events belong to the cross-frame overlap and are created when a frame first asks for it (ensure_overlap_resources)
@@ -387,9 +389,13 @@ struct KernelTimer {   // brackets one launch with an event pair when profiling 
 // The cheaper one runs.  Measured against that model at nine sizes (profiles/r03_exp_widths*.log): within 5 %, same choice as
 // the stopwatch everywhere — lane at 1920, 3840, 1600, 3440, 800 (steps 2-8), 2560 and 1280 (steps 2-8, 32); strip at 1024,
 // 2048, and at steps 16 of 800 / 1280 / 2560.
-static bool lane_pays(const AtrousArgs &a, int n_cu)
+static bool lane_pays(svgf_ctx *c, const AtrousArgs &a)
 {
-    return atrous_lane_estimate_us(a, n_cu) <= atrous_strip_estimate_us(a, n_cu);
+    int l = 0;
+    while ((1 << l) < a.step && l < 7) l++;
+    if (c->lane_cheaper[l] < 0)          // depends on the image size and the device only: evaluated once per context and step
+        c->lane_cheaper[l] = atrous_lane_estimate_us(a, c->n_cu) <= atrous_strip_estimate_us(a, c->n_cu) ? 1 : 0;
+    return c->lane_cheaper[l] != 0;
 }
 
 // gbuffer_dev == nullptr: the planar path (svgf_denoise_planar) — the current-frame planes nrm/pos/gid[1 - gcur] (and `albedo`)
@@ -549,7 +555,7 @@ static int denoise_frame(svgf_ctx *c, void *out_rgb_dev, const void *in_rgb_dev,
                 lattice = !strip && p->kernel_variant != 2 && atrous_lattice_supported(a);     // steps 64, 128, ...
             }
             enum { K_LANE, K_STRIP, K_LATTICE, K_GATHER } which;
-            if (strip && atrous_lane_supported(a) && (p->kernel_variant == 4 || (p->kernel_variant == 0 && lane_pays(a, c->n_cu)))) which = K_LANE;
+            if (strip && atrous_lane_supported(a) && (p->kernel_variant == 4 || (p->kernel_variant == 0 && lane_pays(c, a)))) which = K_LANE;
             else if (strip) which = K_STRIP;
             else if (lattice) which = K_LATTICE;
             else which = K_GATHER;
