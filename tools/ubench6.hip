@@ -52,6 +52,21 @@
 #define FMA_SAMEBANK \
     "v_fma_f32 v8, v32, v36, v8\n v_fma_f32 v12, v32, v36, v12\n v_fma_f32 v16, v32, v36, v16\n v_fma_f32 v20, v32, v36, v20\n v_fma_f32 v24, v32, v36, v24\n v_fma_f32 v28, v32, v36, v28\n v_fma_f32 v44, v32, v36, v44\n v_fma_f32 v48, v32, v36, v48\n" \
     "v_fma_f32 v8, v32, v36, v8\n v_fma_f32 v12, v32, v36, v12\n v_fma_f32 v16, v32, v36, v16\n v_fma_f32 v20, v32, v36, v20\n v_fma_f32 v24, v32, v36, v24\n v_fma_f32 v28, v32, v36, v28\n v_fma_f32 v44, v32, v36, v44\n v_fma_f32 v48, v32, v36, v48\n"
+// two of the three sources in one bank (v32, v36 = bank 0), the accumulator in bank 1
+#define FMA_2SAME \
+    "v_fma_f32 v9, v32, v36, v9\n v_fma_f32 v13, v32, v36, v13\n v_fma_f32 v17, v32, v36, v17\n v_fma_f32 v21, v32, v36, v21\n v_fma_f32 v25, v32, v36, v25\n v_fma_f32 v29, v32, v36, v29\n v_fma_f32 v45, v32, v36, v45\n v_fma_f32 v49, v32, v36, v49\n" \
+    "v_fma_f32 v9, v32, v36, v9\n v_fma_f32 v13, v32, v36, v13\n v_fma_f32 v17, v32, v36, v17\n v_fma_f32 v21, v32, v36, v21\n v_fma_f32 v25, v32, v36, v25\n v_fma_f32 v29, v32, v36, v29\n v_fma_f32 v45, v32, v36, v45\n v_fma_f32 v49, v32, v36, v49\n"
+// one multiplicand and the accumulator in one bank (v32, v8+4k = bank 0), the other multiplicand in bank 1
+#define FMA_2SAME_ACC \
+    "v_fma_f32 v8, v32, v33, v8\n v_fma_f32 v12, v32, v33, v12\n v_fma_f32 v16, v32, v33, v16\n v_fma_f32 v20, v32, v33, v20\n v_fma_f32 v24, v32, v33, v24\n v_fma_f32 v28, v32, v33, v28\n v_fma_f32 v44, v32, v33, v44\n v_fma_f32 v48, v32, v33, v48\n" \
+    "v_fma_f32 v8, v32, v33, v8\n v_fma_f32 v12, v32, v33, v12\n v_fma_f32 v16, v32, v33, v16\n v_fma_f32 v20, v32, v33, v20\n v_fma_f32 v24, v32, v33, v24\n v_fma_f32 v28, v32, v33, v28\n v_fma_f32 v44, v32, v33, v44\n v_fma_f32 v48, v32, v33, v48\n"
+// packed: the three 64-bit sources spread as evenly as four banks allow ({0,1},{2,3},{0,1}) against all three on {0,1}
+#define PKFMA_SPREAD \
+    "v_pk_fma_f32 v[8:9], v[32:33], v[34:35], v[8:9]\n v_pk_fma_f32 v[12:13], v[32:33], v[34:35], v[12:13]\n v_pk_fma_f32 v[16:17], v[32:33], v[34:35], v[16:17]\n v_pk_fma_f32 v[20:21], v[32:33], v[34:35], v[20:21]\n" \
+    "v_pk_fma_f32 v[24:25], v[32:33], v[34:35], v[24:25]\n v_pk_fma_f32 v[28:29], v[32:33], v[34:35], v[28:29]\n v_pk_fma_f32 v[44:45], v[32:33], v[34:35], v[44:45]\n v_pk_fma_f32 v[48:49], v[32:33], v[34:35], v[48:49]\n"
+#define PKFMA_SAME \
+    "v_pk_fma_f32 v[8:9], v[32:33], v[36:37], v[8:9]\n v_pk_fma_f32 v[12:13], v[32:33], v[36:37], v[12:13]\n v_pk_fma_f32 v[16:17], v[32:33], v[36:37], v[16:17]\n v_pk_fma_f32 v[20:21], v[32:33], v[36:37], v[20:21]\n" \
+    "v_pk_fma_f32 v[24:25], v[32:33], v[36:37], v[24:25]\n v_pk_fma_f32 v[28:29], v[32:33], v[36:37], v[28:29]\n v_pk_fma_f32 v[44:45], v[32:33], v[36:37], v[44:45]\n v_pk_fma_f32 v[48:49], v[32:33], v[36:37], v[48:49]\n"
 // 3 distinct banks, dst rotating
 #define FMA_3BANK \
     "v_fma_f32 v8, v33, v34, v8\n v_fma_f32 v12, v33, v34, v12\n v_fma_f32 v16, v33, v34, v16\n v_fma_f32 v20, v33, v34, v20\n v_fma_f32 v24, v33, v34, v24\n v_fma_f32 v28, v33, v34, v28\n v_fma_f32 v44, v33, v34, v44\n v_fma_f32 v48, v33, v34, v48\n" \
@@ -100,7 +115,7 @@ __global__ __launch_bounds__(1024) void k(unsigned long long *out, int reps, flo
     __syncthreads();
     const unsigned lds_addr = (threadIdx.x & 63) * 48u;
     // initialise the registers the bodies read
-    asm volatile("v_mov_b32 v32, %0\n v_mov_b32 v33, %1\n v_mov_b32 v34, %0\n v_mov_b32 v35, %1\n v_mov_b32 v36, %0\n"
+    asm volatile("v_mov_b32 v32, %0\n v_mov_b32 v33, %1\n v_mov_b32 v34, %0\n v_mov_b32 v35, %1\n v_mov_b32 v36, %0\n v_mov_b32 v37, %1\n"
                  "v_mov_b32 v40, %2\n v_mov_b32 v41, %2\n v_mov_b32 v42, %2\n v_mov_b32 v43, %2\n v_mov_b32 v56, %3\n"
                  "v_mov_b32 v8, 0\n v_mov_b32 v9, 0\n v_mov_b32 v10, 0\n v_mov_b32 v11, 0\n v_mov_b32 v12, 0\n v_mov_b32 v13, 0\n v_mov_b32 v14, 0\n v_mov_b32 v15, 0\n"
                  "v_mov_b32 v16, 0\n v_mov_b32 v17, 0\n v_mov_b32 v18, 0\n v_mov_b32 v19, 0\n v_mov_b32 v20, 0\n v_mov_b32 v21, 0\n v_mov_b32 v22, 0\n v_mov_b32 v23, 0\n"
@@ -134,6 +149,10 @@ __global__ __launch_bounds__(1024) void k(unsigned long long *out, int reps, flo
             if (OP == 20) asm volatile(VS16_MUL VS16_MUL ::: CLOB, "s20", "s21", "scc");
             if (OP == 21) asm volatile(VS16_4 VS16_4 ::: CLOB, "s20", "s21", "scc");
             if (OP == 22) asm volatile(VS16_WAIT VS16_WAIT ::: CLOB, "memory");
+            if (OP == 23) asm volatile(FMA_2SAME FMA_2SAME ::: CLOB);
+            if (OP == 24) asm volatile(FMA_2SAME_ACC FMA_2SAME_ACC ::: CLOB);
+            if (OP == 25) asm volatile(PKFMA_SPREAD PKFMA_SPREAD PKFMA_SPREAD PKFMA_SPREAD ::: CLOB);
+            if (OP == 26) asm volatile(PKFMA_SAME PKFMA_SAME PKFMA_SAME PKFMA_SAME ::: CLOB);
         }
         t1 = __builtin_amdgcn_s_memtime();
     }
@@ -181,9 +200,13 @@ int main()
     run<14>("v_add_f32_e32 x32", 32);
     run<11>("v_fma_f32 all operands same bank", 32);
     run<12>("v_fma_f32 three banks", 32);
+    run<23>("v_fma_f32 both multiplicands in one bank", 32);
+    run<24>("v_fma_f32 multiplicand + accumulator in one bank", 32);
     run<13>("v_fma_f32 sgpr source", 32);
     run<15>("v_fma_f32 dependent chain", 32);
     run<3>("v_pk_fma_f32 x32", 32);
+    run<25>("v_pk_fma_f32 sources on banks {0,1},{2,3},{0,1}", 32);
+    run<26>("v_pk_fma_f32 all sources on banks {0,1}", 32);
     run<4>("v_pk_add_f32 x32", 32);
     run<5>("v_pk_mul_f32 x32", 32);
     run<6>("v_exp_f32 x32", 32);
