@@ -29,7 +29,7 @@ EXPORTS = ["svgf_version", "svgf_params_default", "svgf_create", "svgf_destroy",
            "svgf_denoise_host", "svgf_sync", "svgf_last_error", "svgf_width", "svgf_height", "svgf_read_state",
            "svgf_set_capture", "svgf_profile_enable", "svgf_profile_stride", "svgf_profile_frames", "svgf_profile_read",
            "svgf_synth_camera", "svgf_synth_render", "svgf_scene_render", "svgf_scene_render_mesh", "svgf_display_pack", "svgf_save_png",
-           "svgf_planar_gbuffer", "svgf_denoise_planar", "svgf_synth_render_planar", "svgf_params_sizeof"]
+           "svgf_planar_gbuffer", "svgf_denoise_planar", "svgf_synth_render_planar", "svgf_params_sizeof", "svgf_scene_render_mesh_planar"]
 
 
 class SvgfCamera(C.Structure):
@@ -132,6 +132,8 @@ def load_library(path: str | None = None):
                                       C.POINTER(C.c_float), vp]
     lib.svgf_scene_render_mesh.argtypes = [ip, vp, vp, ip, ip, C.POINTER(SvgfCamera), C.POINTER(SvgfSynthParams), vp, ip,
                                            vp, vp, vp, vp, ip, vp, vp, vp, ip, C.POINTER(C.c_float), vp]
+    lib.svgf_scene_render_mesh_planar.argtypes = [ip, vp, C.POINTER(SvgfPlanarGBuffer), ip, ip, C.POINTER(SvgfCamera), C.POINTER(SvgfSynthParams), vp, ip,
+                                                  vp, vp, vp, vp, ip, vp, vp, vp, ip, C.POINTER(C.c_float), vp]
     lib.svgf_planar_gbuffer.argtypes = [vp, C.POINTER(SvgfPlanarGBuffer)]
     lib.svgf_denoise_planar.argtypes = [vp, vp, vp, C.POINTER(SvgfCamera), C.POINTER(SvgfParams), vp]
     lib.svgf_synth_render_planar.argtypes = [ip, vp, C.POINTER(SvgfPlanarGBuffer), ip, ip, C.POINTER(SvgfCamera), C.POINTER(SvgfSynthParams), vp]
@@ -360,7 +362,8 @@ def scene_render_mesh(out_rgb, out_gbuffer, width: int, height: int, camera, geo
                       device: int = 0, stream=None):
     """svgf_scene_render_mesh: primitives (`geoms`, geomId = geom_ids[k]) + world-space triangles (`tris` float32[n,3,8] =
     pos, normal, uv per corner; geomId = tri_ids[i]; albedo = tri_albedo[i]).  The library has read the host arrays completely
-    when it returns (it waits for its uploads); the kernel itself stays asynchronous on `stream`."""
+    when it returns (it waits for its uploads); the kernel itself stays asynchronous on `stream`.
+    `out_gbuffer` may be a SvgfPlanarGBuffer (Denoiser.planar_gbuffer()): svgf_scene_render_mesh_planar writes the planes."""
     from . import scene as _scene
     from . import synth as _synth
     lib = load_library()
@@ -392,12 +395,12 @@ def scene_render_mesh(out_rgb, out_gbuffer, width: int, height: int, camera, geo
     lp = _scene.light_position(geoms) if light is None else np.asarray(light, dtype=np.float32)
     larr = (C.c_float * 3)(float(lp[0]), float(lp[1]), float(lp[2]))
     s = None if stream is None else (stream if isinstance(stream, int) else stream.cuda_stream)
-    rc = lib.svgf_scene_render_mesh(int(device), _ptr(out_rgb), _ptr(out_gbuffer), int(width), int(height), C.byref(cam), C.byref(sp),
-                                    geoms.ctypes.data if len(geoms) else None, int(len(geoms)), gi.ctypes.data if len(gi) else None,
-                                    tr.ctypes.data if len(tr) else None, ti.ctypes.data if len(ti) else None,
-                                    ta.ctypes.data if len(ta) else None, int(len(tr)),
-                                    tt.ctypes.data if n_tex else None, td.ctypes.data if n_tex else None, tx.ctypes.data if n_tex else None,
-                                    int(n_tex), larr, s)
+    planar = isinstance(out_gbuffer, SvgfPlanarGBuffer)
+    fn = lib.svgf_scene_render_mesh_planar if planar else lib.svgf_scene_render_mesh
+    rc = fn(int(device), _ptr(out_rgb), C.byref(out_gbuffer) if planar else _ptr(out_gbuffer), int(width), int(height), C.byref(cam), C.byref(sp),
+            geoms.ctypes.data if len(geoms) else None, int(len(geoms)), gi.ctypes.data if len(gi) else None,
+            tr.ctypes.data if len(tr) else None, ti.ctypes.data if len(ti) else None, ta.ctypes.data if len(ta) else None, int(len(tr)),
+            tt.ctypes.data if n_tex else None, td.ctypes.data if n_tex else None, tx.ctypes.data if n_tex else None, int(n_tex), larr, s)
     if rc != SVGF_OK:
         raise SvgfError(f"svgf_scene_render_mesh failed ({rc})")
     if stream is None:

@@ -32,7 +32,9 @@ struct SceneArgs {
     const int *tex_desc;       // per texture {byte offset into tex, width, height}, 8-bit RGB rows top to bottom
     const unsigned char *tex;
     float *out_rgb;
-    float *out_gbuf;
+    float *out_gbuf;           // AoS texels, or null: the planes below (svgf_planar_gbuffer)
+    float *pl_nrm, *pl_pos, *pl_alb;
+    int *pl_gid;
 };
 
 __device__ __forceinline__ float scene_hash(unsigned seed, unsigned frame, unsigned p, unsigned k)
@@ -193,6 +195,13 @@ __global__ __launch_bounds__(256) void k_scene_frame(SceneArgs a)
     }
     float *o_rgb = a.out_rgb + 3 * (size_t)p;
     o_rgb[0] = col[0]; o_rgb[1] = col[1]; o_rgb[2] = col[2];
+    if (!a.out_gbuf) {        // planar: the denoiser's own current-frame planes; albedo * ialbedo with ialbedo == 1
+        a.pl_nrm[3 * (size_t)p] = n[0]; a.pl_nrm[3 * (size_t)p + 1] = n[1]; a.pl_nrm[3 * (size_t)p + 2] = n[2];
+        a.pl_pos[3 * (size_t)p] = pos[0]; a.pl_pos[3 * (size_t)p + 1] = pos[1]; a.pl_pos[3 * (size_t)p + 2] = pos[2];
+        if (a.pl_alb) { a.pl_alb[3 * (size_t)p] = alb[0]; a.pl_alb[3 * (size_t)p + 1] = alb[1]; a.pl_alb[3 * (size_t)p + 2] = alb[2]; }
+        a.pl_gid[p] = gid;
+        return;
+    }
     float *g = a.out_gbuf + 13 * (size_t)p;
     g[0] = n[0]; g[1] = n[1]; g[2] = n[2];
     g[3] = pos[0]; g[4] = pos[1]; g[5] = pos[2];
@@ -203,13 +212,14 @@ __global__ __launch_bounds__(256) void k_scene_frame(SceneArgs a)
 
 }  // namespace
 
-extern "C" int svgf_scene_render_mesh(int device, void *out_rgb_dev, void *out_gbuffer_dev, int width, int height,
-                                      const SvgfCamera *cam, const SvgfSynthParams *sp, const SvgfSceneGeom *geoms, int n_geoms,
-                                      const int *geom_ids, const float *tris, const int *tri_ids, const float *tri_albedo, int n_tris,
-                                      const int *tri_tex, const int *tex_desc, const unsigned char *tex_data, int n_tex,
-                                      const float light[3], void *stream)
+static int scene_render_impl(int device, void *out_rgb_dev, void *out_gbuffer_dev, const SvgfPlanarGBuffer *planes, int width, int height,
+                             const SvgfCamera *cam, const SvgfSynthParams *sp, const SvgfSceneGeom *geoms, int n_geoms,
+                             const int *geom_ids, const float *tris, const int *tri_ids, const float *tri_albedo, int n_tris,
+                             const int *tri_tex, const int *tex_desc, const unsigned char *tex_data, int n_tex,
+                             const float light[3], void *stream)
 {
-    if (!out_rgb_dev || !out_gbuffer_dev || !cam || !sp || !light || width <= 0 || height <= 0) return SVGF_ERR_INVALID_ARG;
+    if (!out_rgb_dev || (!out_gbuffer_dev && !planes) || !cam || !sp || !light || width <= 0 || height <= 0) return SVGF_ERR_INVALID_ARG;
+    if (!out_gbuffer_dev && (!planes->normal || !planes->position || !planes->geom_id)) return SVGF_ERR_INVALID_ARG;
     if (n_geoms < 0 || n_geoms > SVGF_SCENE_MAX_GEOMS || (n_geoms > 0 && !geoms)) return SVGF_ERR_INVALID_ARG;
     if (n_tris < 0 || n_tris > SVGF_SCENE_MAX_TRIS || (n_tris > 0 && (!tris || !tri_ids || !tri_albedo))) return SVGF_ERR_INVALID_ARG;
     if (n_tex < 0 || n_tex > 64 || (n_tex > 0 && (!tri_tex || !tex_desc || !tex_data || n_tris == 0))) return SVGF_ERR_INVALID_ARG;
@@ -268,11 +278,36 @@ extern "C" int svgf_scene_render_mesh(int device, void *out_rgb_dev, void *out_g
     a.tex = reinterpret_cast<const unsigned char *>(d + o_tex);
     a.out_rgb = static_cast<float *>(out_rgb_dev);
     a.out_gbuf = static_cast<float *>(out_gbuffer_dev);
+    a.pl_nrm = planes ? planes->normal : nullptr; a.pl_pos = planes ? planes->position : nullptr;
+    a.pl_alb = planes ? planes->albedo : nullptr; a.pl_gid = planes ? planes->geom_id : nullptr;
     const int n = width * height;
     hipLaunchKernelGGL(k_scene_frame, dim3((n + 255) / 256), dim3(256), 0, s, a);
     const hipError_t e = hipGetLastError();
     (void)hipFreeAsync(d, s);
     return e == hipSuccess ? SVGF_OK : SVGF_ERR_HIP;
+}
+
+extern "C" int svgf_scene_render_mesh(int device, void *out_rgb_dev, void *out_gbuffer_dev, int width, int height,
+                                      const SvgfCamera *cam, const SvgfSynthParams *sp, const SvgfSceneGeom *geoms, int n_geoms,
+                                      const int *geom_ids, const float *tris, const int *tri_ids, const float *tri_albedo, int n_tris,
+                                      const int *tri_tex, const int *tex_desc, const unsigned char *tex_data, int n_tex,
+                                      const float light[3], void *stream)
+{
+    if (!out_gbuffer_dev) return SVGF_ERR_INVALID_ARG;
+    return scene_render_impl(device, out_rgb_dev, out_gbuffer_dev, nullptr, width, height, cam, sp, geoms, n_geoms, geom_ids, tris, tri_ids,
+                             tri_albedo, n_tris, tri_tex, tex_desc, tex_data, n_tex, light, stream);
+}
+
+// the same frame written into the planes of svgf_planar_gbuffer (the repack fused into the producer)
+extern "C" int svgf_scene_render_mesh_planar(int device, void *out_rgb_dev, const SvgfPlanarGBuffer *out_planes, int width, int height,
+                                             const SvgfCamera *cam, const SvgfSynthParams *sp, const SvgfSceneGeom *geoms, int n_geoms,
+                                             const int *geom_ids, const float *tris, const int *tri_ids, const float *tri_albedo, int n_tris,
+                                             const int *tri_tex, const int *tex_desc, const unsigned char *tex_data, int n_tex,
+                                             const float light[3], void *stream)
+{
+    if (!out_planes) return SVGF_ERR_INVALID_ARG;
+    return scene_render_impl(device, out_rgb_dev, nullptr, out_planes, width, height, cam, sp, geoms, n_geoms, geom_ids, tris, tri_ids,
+                             tri_albedo, n_tris, tri_tex, tex_desc, tex_data, n_tex, light, stream);
 }
 
 extern "C" int svgf_scene_render(int device, void *out_rgb_dev, void *out_gbuffer_dev, int width, int height,

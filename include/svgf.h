@@ -32,7 +32,7 @@ extern "C" {
 #endif
 
 #define SVGF_VERSION_MAJOR 0
-#define SVGF_VERSION_MINOR 4
+#define SVGF_VERSION_MINOR 5
 
 /* ---- error codes (every entry point returns one of these; the library never exits) ---- */
 #define SVGF_OK                 0
@@ -270,6 +270,13 @@ int svgf_scene_render_mesh(int device, void *out_rgb_dev, void *out_gbuffer_dev,
                            const int *geom_ids, const float *tris, const int *tri_ids, const float *tri_albedo, int n_tris,
                            const int *tri_tex, const int *tex_desc, const unsigned char *tex_data, int n_tex,
                            const float light[3], void *stream);
+/* The same frame written into the planes of svgf_planar_gbuffer instead of AoS texels (same pixels, same values; n_geoms and
+ * n_tris may each be 0): the producer side of svgf_denoise_planar for scenes in the reference's format. */
+int svgf_scene_render_mesh_planar(int device, void *out_rgb_dev, const SvgfPlanarGBuffer *out_planes, int width, int height,
+                                  const SvgfCamera *cam, const SvgfSynthParams *sp, const SvgfSceneGeom *geoms, int n_geoms,
+                                  const int *geom_ids, const float *tris, const int *tri_ids, const float *tri_albedo, int n_tris,
+                                  const int *tri_tex, const int *tex_desc, const unsigned char *tex_data, int n_tex,
+                                  const float light[3], void *stream);
 
 /* ---- "next" row f2: the step right after denoise() ------------------------------------------------
  * svgf_display_pack: reference sendTwoImagesToPBO (src/pathtrace.cu:45-77, launched at :446): `left` (the 1-spp

@@ -100,6 +100,47 @@ def test_device_producer_writing_planes_equals_the_one_writing_texels(pkg):
         assert np.array_equal(a, b)
 
 
+def test_scene_producer_writing_planes_equals_the_one_writing_texels(pkg):
+    """svgf_scene_render_mesh_planar -> svgf_denoise_planar against svgf_scene_render_mesh -> svgf_denoise on room.txt's
+    primitives + 2 810 mesh triangles (the reference's scene, tests/golden/ref_scenes/room_producer_inputs.npz) with the
+    reference's camera automation, 4 moving frames at 480x270, sepcolor + addcolor on so that the albedo plane is read:
+    bit-identical outputs and history."""
+    import json
+    import os
+    import torch
+    from conftest import ROOT
+    DIR = os.path.join(ROOT, "tests", "golden", "ref_scenes")
+    W, H, N = 480, 270, 4
+    pi = np.load(os.path.join(DIR, "room_producer_inputs.npz"))
+    rec = json.load(open(os.path.join(DIR, "scene_records.json")))["room"]["camera"]
+    sc = pkg.scene.Scene(materials={}, objects=[], camera=dict(eye=rec["position"], lookat=rec["lookAt"], fovy=rec["fov"][1]), skipped=[])
+    p = pkg.reference_defaults().set(temporal_enable=1, spatial_enable=1, sepcolor=1, addcolor=1)
+    rgb = torch.empty((H, W, 3), dtype=torch.float32, device="cuda")
+    gbt = torch.empty((H * W * 52,), dtype=torch.uint8, device="cuda")
+    res = {}
+    for planar in (False, True):
+        d = pkg.Denoiser(W, H, 0)
+        outs = []
+        out = torch.empty((H, W, 3), dtype=torch.float32, device="cuda")
+        for f in range(N):
+            cam = pkg.scene.camera_for_frame(sc, f, True)
+            target = d.planar_gbuffer() if planar else gbt
+            pkg.binding.scene_render_mesh(rgb, target, W, H, cam, pi["geoms"], pi["geom_ids"], pi["tris"], pi["tri_ids"], pi["tri_albedo"], frame=f)
+            if planar:
+                d.denoise_planar(out, rgb, cam, p)
+            else:
+                d.denoise(out, rgb, gbt, cam, p)
+            torch.cuda.synchronize()
+            outs.append(out.cpu().numpy().copy())
+        res[planar] = (outs, d.read_state(0), d.read_state(1), d.read_state(2))
+        d.free()
+    assert np.isfinite(res[False][0][-1]).all() and res[False][0][-1].max() > 0
+    for f in range(N):
+        assert np.array_equal(res[False][0][f], res[True][0][f]), f"frame {f}"
+    for a, b in zip(res[False][1:], res[True][1:]):
+        assert np.array_equal(a, b)
+
+
 def test_planar_and_aos_frames_alternate_on_one_context(pkg):
     """The planes rotate with the history whichever entry point fed them: alternating frames equal an all-AoS run."""
     import torch
