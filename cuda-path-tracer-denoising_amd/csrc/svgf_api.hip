@@ -21,7 +21,7 @@ struct svgf_ctx {
     int device, W, H;
     size_t n;
     float4 *cv[4];
-    float *vp[4];          // zero-margined (W+2) x (H+2) copies of cv[k].w for the pre-blur of the per-wave a-trous kernel
+    float *vp[4];          // zero-margined (W+2) x (H+2) copies of cv[k].w: what the step-16/32 levels take their 3x3 variance pre-blur from
     unsigned vp_valid;     // bit k: vp[k] holds the variance of cv[k]
     int use_vplane;        // 0 only for A/B measurements (environment SVGF_NO_VARIANCE_PLANE at svgf_create)
     int n_cu;              // compute units of the context's device (launch-geometry cost model of the kernel choice)
