@@ -13,6 +13,8 @@
 //       its forward term (-i, +j), so it arrives by a DPP wave shift of |i| lanes (v_mov_b32_dpp wave_shr/wave_shl:1,
 //       which the compiler folds into the consuming VALU op where it can).
 // 12 geometry evaluations per output pixel instead of 24, no extra LDS traffic, no extra barrier.
+// The same ownership gives the backward and left-hand taps their LUMINANCE without LDS: it is the centre luminance the owning
+// lane held one or two iterations ago (or holds now), four lane shifts away.
 //
 // For the partner of column x +- i to be lane +- i, the 64 lanes of a wave hold 64 consecutive columns of ONE x-phase
 // (pixel columns x, x+S, x+2S, ...): the LDS ring stores every row phase-major ([phase][lattice column], 48-byte
@@ -30,9 +32,6 @@
 #include <cstdlib>
 #include <type_traits>
 
-#ifndef SVGF_LANE_G2
-#define SVGF_LANE_G2 2      // where the second forward row's geometry is read: 0 one row ahead, 1 mid-row, 2 not ahead
-#endif
 #ifndef SVGF_LANE_SPLIT_PROLOGUE
 #define SVGF_LANE_SPLIT_PROLOGUE 1
 #endif
@@ -44,9 +43,6 @@
 #endif
 #ifndef SVGF_LANE_LOADER_PRIO
 #define SVGF_LANE_LOADER_PRIO 2
-#endif
-#ifndef SVGF_LANE_G1
-#define SVGF_LANE_G1 1      // first forward row's geometry read one row ahead (1) or not (0)
 #endif
 
 namespace {
@@ -540,22 +536,14 @@ __global__ __launch_bounds__(NT) void k_atrous_lane(AtrousArgs a, LaneGeom gm)
         }
     };
 
-#ifndef SVGF_LANE_LUM_B128_ALL
-#define SVGF_LANE_LUM_B128_ALL 1
-#endif
-    constexpr bool LUM_B128 = HASVAR || SVGF_LANE_LUM_B128_ALL;
-    struct ColRow { v4f C[5]; float l[5]; };              // colour-only row: colour slot + luminance of the 5 taps
+    struct ColRow { v4f C[5]; };                          // backward row: colour slots (luminance comes from the owning lanes, see do_col)
     struct GeoRow { v4f A[5], B[5]; };                    // forward row: geometry slots (the colour slot is read mid-row)
-    struct OwnRow { v4f A[2], B[2], C[2], Cb[2]; float l[2]; };   // own row: +1, +2 full records; -1, -2 colour + luminance
+    struct OwnRow { v4f A[2], B[2], C[2], Cb[2]; };       // own row: +1, +2 full records; -1, -2 colour
     auto load_col = [&](ColRow &r, int br) {
         const char *rowp = colbase + slot_of(br) * ROWB;
 #pragma unroll
         for (int i = 0; i < 5; i++) {
             r.C[i] = *reinterpret_cast<const v4f *>(rowp + i * PXB + 32);
-            // luminance: the whole B slot as a b128 (conflict-free at the 48-byte lane stride; an 8-byte read of {lum, pad}
-            // is 2-way conflicted: lanes 16 apart share banks)
-            if constexpr (LUM_B128) r.l[i] = reinterpret_cast<const v4f *>(rowp + i * PXB + 16)->z;
-            else r.l[i] = reinterpret_cast<const v2f *>(rowp + i * PXB + 24)->x;
         }
     };
     auto load_geo = [&](GeoRow &r, int br) {
@@ -574,14 +562,19 @@ __global__ __launch_bounds__(NT) void k_atrous_lane(AtrousArgs a, LaneGeom gm)
             r.B[k] = *reinterpret_cast<const v4f *>(rowp + (k + 3) * PXB + 16);
             r.C[k] = *reinterpret_cast<const v4f *>(rowp + (k + 3) * PXB + 32);
             r.Cb[k] = *reinterpret_cast<const v4f *>(rowp + (1 - k) * PXB + 32);
-            if constexpr (LUM_B128) r.l[k] = reinterpret_cast<const v4f *>(rowp + (1 - k) * PXB + 16)->z;
-            else r.l[k] = reinterpret_cast<const v2f *>(rowp + (1 - k) * PXB + 24)->x;
         }
     };
-    auto do_col = [&](Acc &acc, const ColRow &r, const float (&tt)[5], float lp, float kl) {
+    // Backward row.  The taps' geometry terms come from the queue, and their LUMINANCE from registers too: lpH is the luminance
+    // this lane had as the CENTRE of that row, one or two iterations ago; tap column x + io is lane + io, whose centre luminance
+    // of that row is exactly the tap's (out-of-image pixels carry +inf in both places).  Four lane shifts instead of five 16-byte
+    // LDS reads, in the rows whose VALU work is too short to hide LDS reads (profiles/r03_exp_lane_knockout.log: eight reads of
+    // the backward rows cost 4.8 % of a level, the same eight in the forward rows 1.6 %), and 20 VGPRs fewer
+    // (profiles/r03_ab_lane_lum_dpp.log: -1.1 us per level, -1.9 on the last).
+    auto do_col = [&](Acc &acc, const ColRow &r, const float (&tt)[5], float lp, float kl, float lpH) {
         float e[5], w[5];
-#pragma unroll
-        for (int i = 0; i < 5; i++) e[i] = fmaf(fabsf(r.l[i] - lp), kl, tt[i]);
+        const float l0 = lane_from<-2>(lpH), l1 = lane_from<-1>(lpH), l3 = lane_from<1>(lpH), l4 = lane_from<2>(lpH);
+        e[0] = fmaf(fabsf(l0 - lp), kl, tt[0]); e[1] = fmaf(fabsf(l1 - lp), kl, tt[1]); e[2] = fmaf(fabsf(lpH - lp), kl, tt[2]);
+        e[3] = fmaf(fabsf(l3 - lp), kl, tt[3]); e[4] = fmaf(fabsf(l4 - lp), kl, tt[4]);
         __builtin_amdgcn_sched_barrier(0x100);
 #pragma unroll
         for (int i = 0; i < 5; i++) w[i] = __builtin_amdgcn_exp2f(-e[i]);
@@ -634,6 +627,7 @@ __global__ __launch_bounds__(NT) void k_atrous_lane(AtrousArgs a, LaneGeom gm)
     };
 
     // ---- warm-up: rows b0-2 and b0-1 publish their forward terms (no output, no new ring rows needed) ----
+    float lp1 = 0.0f, lp2 = 0.0f;          // this lane's centre luminance one / two rows back
 #pragma unroll 1
     for (int bw = b0 - 2; bw < b0; bw++) {
 #if SVGF_LANE_SPLIT_PROLOGUE
@@ -642,6 +636,7 @@ __global__ __launch_bounds__(NT) void k_atrous_lane(AtrousArgs a, LaneGeom gm)
         const char *rowc = colbase + slot_of(bw) * ROWB + 2 * PXB;
         const v4f A = *reinterpret_cast<const v4f *>(rowc);
         const v4f B = *reinterpret_cast<const v4f *>(rowc + 16);
+        lp2 = lp1; lp1 = B.z;
         float F1[5] = { 0.0f, 0.0f, 0.0f, 0.0f, 0.0f }, F2[5];
 #pragma unroll
         for (int j = 1; j <= 2; j++) {
@@ -765,8 +760,9 @@ __global__ __launch_bounds__(NT) void k_atrous_lane(AtrousArgs a, LaneGeom gm)
                 tf[k] = fmaf(dx, kx, t);
             }
             const float tb1 = lane_from<-1>(tf[0]), tb2 = lane_from<-2>(tf[1]);
-            e[0] = fmaf(fabsf(r2.l[1] - lp), kl, tb2);          // io = -2
-            e[1] = fmaf(fabsf(r2.l[0] - lp), kl, tb1);          // io = -1
+            const float ll2 = lane_from<-2>(lp), ll1 = lane_from<-1>(lp);      // the left-hand neighbours' luminance: their centre's
+            e[0] = fmaf(fabsf(ll2 - lp), kl, tb2);          // io = -2
+            e[1] = fmaf(fabsf(ll1 - lp), kl, tb1);          // io = -1
             e[2] = fmaf(fabsf(r2.B[0].z - lp), kl, tf[0]);      // io = +1
             e[3] = fmaf(fabsf(r2.B[1].z - lp), kl, tf[1]);      // io = +2
             __builtin_amdgcn_sched_barrier(0x100);
@@ -785,11 +781,11 @@ __global__ __launch_bounds__(NT) void k_atrous_lane(AtrousArgs a, LaneGeom gm)
             // backward rows: colour part only; t comes from the queue (already moved to this lane by publish())
             ColRow r1;
             load_col(r1, bo - 1);
-            do_col(acc, r0, ppF2, lp, kl);
+            do_col(acc, r0, ppF2, lp, kl, lp2);
             OwnRow r2;
             load_own(r2, bo);
             row_fence(acc);
-            do_col(acc, r1, pF1, lp, kl);
+            do_col(acc, r1, pF1, lp, kl, lp1);
             __builtin_amdgcn_s_setprio(PR[1]);              // ~1/4 of the row's work done
             load_geo(g1, bo + 1);
             row_fence(acc);
@@ -827,9 +823,9 @@ __global__ __launch_bounds__(NT) void k_atrous_lane(AtrousArgs a, LaneGeom gm)
             row_fence(acc);
             ColRow r1;
             load_col(r1, bo - 1);
-            do_col(acc, r0, ppF2, lp, kl);
+            do_col(acc, r0, ppF2, lp, kl, lp2);
             row_fence(acc);
-            do_col(acc, r1, pF1, lp, kl);
+            do_col(acc, r1, pF1, lp, kl, lp1);
             row_fence(acc);
         }
         publish(F1, F2);
@@ -855,6 +851,7 @@ __global__ __launch_bounds__(NT) void k_atrous_lane(AtrousArgs a, LaneGeom gm)
             if (a.out_rgb) { float *o = a.out_rgb + 3u * p; o[0] = o0; o[1] = o1; o[2] = o2; }
         }
         if constexpr (PREFETCH_CENTRE) cen = nxt;
+        lp2 = lp1; lp1 = lp;
     };
 
     int it = 0;
