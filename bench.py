@@ -9,9 +9,13 @@ history rotation) over one 1920x1080 frame of the synthetic Cornell-like sequenc
 are resident in HBM before the timed region starts.  N > 1: one process and one SVGF context per GPU, every rank
 denoises its own independent sequence (weak scaling, no data-path collective); value = pixels of all ranks / max time.
 
-Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (the a-trous level): algorithmic bytes per launch
-(56 B/pixel) / mean launch duration from HIP events recorded on the launch stream inside the timed
-region.  `cpu_baseline` (N == 1 only) times the CPU oracle — a port, not the product — on the host cores.
+Rank 0 prints ONE JSON line.  `value` is the pipelined throughput (K calls enqueued back to back, one synchronisation at
+the end); `latency_ms_sync` is the metric as SURVEY.md §8(d)(i) words it — the median wall time of one svgf_denoise +
+svgf_sync pair, what the reference's synchronous denoise() (src/denoise.cu:401) gives its caller.  `roofline` is for the
+dominant kernel (the a-trous level): algorithmic bytes per launch (56 B/pixel) / mean launch duration from
+HIP events recorded on the launch stream inside the timed region.  `telemetry` holds shader clock / power / temperature
+sampled while each of the three measurements ran (tools/telemetry.py).  `cpu_baseline` (N == 1 only) times the CPU oracle —
+a port, not the product — on the host cores.
 """
 from __future__ import annotations
 
@@ -25,7 +29,9 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
 import __graft_entry__ as ge  # noqa: E402
+import telemetry  # noqa: E402
 
 W, H = 1920, 1080
 NLEVEL = 5
@@ -38,7 +44,7 @@ def kernel_sources_sha16():
     """Fingerprint of the a-trous kernel sources the PMC traffic record belongs to."""
     import hashlib
     h = hashlib.sha256()
-    for name in ("svgf_atrous_lane.hip", "svgf_atrous_strip.hip", "svgf_api.hip"):
+    for name in ("svgf_atrous_lane_impl.h", "svgf_atrous_lane.hip", "svgf_atrous_fused.hip", "svgf_atrous_strip.hip", "svgf_api.hip"):
         with open(os.path.join(ROOT, "cuda-path-tracer-denoising_amd", "csrc", name), "rb") as f:
             h.update(f.read())
     return h.hexdigest()[:16]
@@ -113,6 +119,8 @@ def cpu_baseline(pkg, frames, params, budget_s=25.0, threads=None, what="full-SV
             break
     o.free()
     res = {"value": round(W * H / (t_all / n) / 1e6, 3), "unit": "Mpixels/s", "cores": threads, "kind": "port",
+           "kind_note": "oracle/svgf_oracle.c, the CPU restatement of src/denoise.cu pinned to the reference's own outputs (SURVEY.md 8(d) "
+                        "allows it as the CPU baseline); NOT the reference's source rebuilt for CPU, which north_star words",
            "sample": f"{n} steady-state frames of the same {W}x{H} {what} workload, oracle/svgf_oracle.c "
                      f"(gcc -O2, OpenMP static row blocks, threads bound to cores; {threads} threads; host: {cores} physical cores, "
                      f"{os.cpu_count()} hardware threads, {cpu_model}; container CPU quota: {quota if quota else 'none'})",
@@ -145,9 +153,11 @@ def main():
     ap.add_argument("--kernel-variant", type=int, default=0,
                     help="SvgfParams::kernel_variant (0 = the library's default choice; 2 strip, 4 lane-marching kernel ...)")
     ap.add_argument("--overlap", action="store_true",
-                    help="SvgfParams::inputs_ready = 1: the next frame's temporal pass runs on an internal stream beside the trailing "
-                         "a-trous levels (opt-in: measured +2.0 % at 1080p, +1.6 % at 4K, profiles/r02_exp_overlap_ab.log)")
-    ap.add_argument("--no-overlap", action="store_true", help="(default since round 2; kept so that old command lines still run)")
+                    help="no effect since round 4: SvgfParams::inputs_ready is accepted and ignored (the cross-frame overlap lost 3-8 %% "
+                         "in round 3 and the fused first level removed the pass it hid); kept so that old command lines still run")
+    ap.add_argument("--no-overlap", action="store_true", help="(no effect; kept so that old command lines still run)")
+    ap.add_argument("--latency-calls", type=int, default=60,
+                    help="svgf_denoise + svgf_sync pairs of the latency measurement (SURVEY.md 8(d)(i): median of >= 50 after 10 warm-ups)")
     ap.add_argument("--host-inputs", action="store_true",
                     help="render the synthetic frames with numpy and upload them (default: the device-side producer, "
                          "svgf_synth_render, SURVEY.md 8f row f1; both give the same frames bit for bit)")
@@ -214,8 +224,7 @@ def main():
     if dist is not None:
         dist.barrier()
     pkg = ge.load_package()
-    params = pkg.reference_defaults().set(temporal_enable=1, spatial_enable=1, atrous_nlevel=NLEVEL, history_level=1,
-                                          inputs_ready=1 if (a.overlap and not a.no_overlap) else 0)   # inputs are resident in HBM before each call
+    params = pkg.reference_defaults().set(temporal_enable=1, spatial_enable=1, atrous_nlevel=NLEVEL, history_level=1)
     params.set(kernel_variant=a.kernel_variant)
     if a.config == "config1":   # BASELINE configs[0]: the reference's own CPU-runnable case
         params.set(temporal_enable=0, atrous_nlevel=1)
@@ -270,31 +279,54 @@ def main():
             torch.cuda.synchronize(dev)
     torch.cuda.synchronize(dev)
     den.profile_enable(a.steps)
+    tm_all = telemetry.Sampler(local_rank).start()
+    t_region0 = time.perf_counter()
     dt, pixels = pkg.farm.timed_region(step, a.steps, 0, lambda: torch.cuda.synchronize(dev), dist=dist, device=dev)
+    t_region1 = time.perf_counter()
 
     # per-kernel durations of the timed steps (HIP events on the launch stream)
-    atrous_ms, temporal_ms = [], []
+    atrous_ms, temporal_ms, fused_ms = [], [], []
     for s in range(min(a.steps, den.profile_frames())):
         for kind, ms in den.profile_read(s):
             if kind == pkg.binding.KERNEL_ATROUS:
                 atrous_ms.append(ms)
             elif kind == pkg.binding.KERNEL_TEMPORAL:
                 temporal_ms.append(ms)
+            elif kind == pkg.binding.KERNEL_FUSED:
+                fused_ms.append(ms)
+
+    # The metric as SURVEY.md 8(d)(i) defines it: wall time of ONE svgf_denoise call, device-synchronised (what the reference's
+    # synchronous denoise() delivers, src/denoise.cu:401), median of >= 50 calls after 10 warm-ups.  No per-kernel events; it
+    # follows the timed region directly, so the clocks are the sustained ones (the telemetry of the two is reported side by side).
+    den.profile_enable(0)
+    for i in range(10):
+        step(i); den.sync()
+    lat = []
+    t_lat0 = time.perf_counter()
+    for i in range(max(50, a.latency_calls)):
+        t0 = time.perf_counter()
+        step(i)
+        den.sync()
+        lat.append(time.perf_counter() - t0)
+    t_lat1 = time.perf_counter()
+    lat_ms = np.asarray(lat) * 1e3
     if not np.isfinite(out.sum().item()):
         raise SystemExit("bench: non-finite output")
 
     # the same kernels timed in isolation (outside the timed region): cross-frame overlap off, so no a-trous level shares
     # the GPU with the next frame's temporal pass; events around every kernel of 16 frames
-    iso_params = pkg.reference_defaults().set(temporal_enable=1, spatial_enable=1, atrous_nlevel=NLEVEL, history_level=1,
-                                              inputs_ready=0)
+    iso_params = pkg.reference_defaults().set(temporal_enable=1, spatial_enable=1, atrous_nlevel=NLEVEL, history_level=1)
     iso_params.set(kernel_variant=a.kernel_variant)
     if a.config == "config1":
         iso_params.set(temporal_enable=0, atrous_nlevel=1)
     den.profile_stride(1)
     den.profile_enable(16)
+    t_iso0 = time.perf_counter()
     for i in range(16):
         den.denoise(out, d_in[i % nsrc], d_g[i % nsrc], cams[i % nsrc], iso_params, stream=stream)
     torch.cuda.synchronize(dev)
+    t_iso1 = time.perf_counter()
+    tm_all.stop()
     iso_atrous_ms = [ms for s in range(den.profile_frames()) for kind, ms in den.profile_read(s)
                      if kind == pkg.binding.KERNEL_ATROUS]
 
@@ -322,6 +354,14 @@ def main():
             "value": round(value, 2), "unit": "Mpixels/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "warmup_steps_run": n_w,
             "ms_per_step": round(dt / a.steps * 1e3, 5), "higher_is_better": True, "scaling": "weak",
+            # one svgf_denoise + svgf_sync, median of the calls below (host wall clock around the pair)
+            "latency_ms_sync": round(float(np.median(lat_ms)), 5),
+            "latency": {"calls": len(lat), "warmup_calls": 10, "median_ms": round(float(np.median(lat_ms)), 5),
+                        "p10_ms": round(float(np.quantile(lat_ms, 0.1)), 5), "p90_ms": round(float(np.quantile(lat_ms, 0.9)), 5),
+                        "mpixels_per_s": round(W * H / (float(np.median(lat_ms)) * 1e-3) / 1e6, 1),
+                        "what": "wall time of svgf_denoise + svgf_sync per call (rank 0), what the reference's synchronous denoise() gives its caller"},
+            "telemetry": {"timed_region": tm_all.summary(t_region0, t_region1), "latency_calls": tm_all.summary(t_lat0, t_lat1),
+                          "isolated_16_frames": tm_all.summary(t_iso0, t_iso1)},
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": (f"cornell-like {W}x{H}, variance fill + ONE a-trous level (temporal off), " if a.config == "config1" else
                                     f"cornell-like {W}x{H}, full SVGF (temporal + 5 a-trous levels, history_level 1), ")
@@ -334,11 +374,9 @@ def main():
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "traffic_measured_live": False, "traffic_provenance": traffic_note,
                          "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, profiles/pmc_traffic.json (FETCH x2 per MI355X_MICROARCH.md)",
-                         "kernel": "one a-trous level: k_atrous_lane (steps 2-32 at 1920 / 3840 / 800 columns; k_atrous_strip where the library's width heuristic prefers it); mean over the a-trous launches of a frame", "bytes_per_launch": ATROUS_BYTES_PER_PIXEL * W * H,
+                         "kernel": "one plain a-trous level: k_atrous_lane (steps 4-32 when the first level is fused with the temporal pass, else 2-32; k_atrous_strip where the library's cost model prefers it); mean over those launches of a frame; the fused temporal + first-level launch is reported under kernels_us", "bytes_per_launch": ATROUS_BYTES_PER_PIXEL * W * H,
                          "mean_launch_us": round(a_ms * 1e3, 2), "launches_timed": len(atrous_ms),
-                         "note": ("timed-region launches include levels that run beside the next frame's temporal pass "
-                                  "(cross-frame overlap, --overlap); 'isolated' is the same kernel with the GPU to itself") if (a.overlap and not a.no_overlap)
-                                 else "everything ordered on one stream (cross-frame overlap is opt-in: --overlap); 'isolated' repeats the measurement with events around every kernel of 16 frames",
+                         "note": "everything ordered on one stream; 'isolated' repeats the measurement with events around every kernel of 16 frames",
                          "isolated": {"mean_launch_us": round(iso_us, 2), "achieved": round(iso_gbs, 1),
                                       "frac": round(iso_gbs / HBM_PEAK_GBS, 4), "launches_timed": len(iso_atrous_ms)},
                          # the secondary limiter.  24 taps x (2 v_sqrt + 1 v_exp) + 5 (centre, normalisation) per pixel-level
@@ -349,7 +387,8 @@ def main():
                          "valu_view": {"fp32_tflops_isolated": round(950 * W * H / (iso_us * 1e-6) / 1e12, 1),
                                        "fp32_vector_peak_tflops": 157.3, "simd_instruction_active_pmc": 1.0}},
             "kernels_us": {"temporal": round(float(np.mean(temporal_ms)) * 1e3, 2) if temporal_ms else None,
-                           "atrous_level_mean": round(a_ms * 1e3, 2)},
+                           "fused_temporal_plus_level1": round(float(np.mean(fused_ms)) * 1e3, 2) if fused_ms else None,
+                           "atrous_level_mean": round(a_ms * 1e3, 2), "atrous_launches_per_frame": round(len(atrous_ms) / max(1, len(fused_ms) + len(temporal_ms)), 2) if (fused_ms or temporal_ms) else None},
             "frame_algorithmic_gbs": round((ATROUS_BYTES_PER_PIXEL if a.config == "config1" else FRAME_BYTES_PER_PIXEL)
                                            * W * H / (dt / a.steps) / 1e9 / world * 1.0, 1),
         }

@@ -21,7 +21,7 @@ LIB_PATH = os.path.join(_HERE, "libsvgf_hip.so")
 
 SVGF_OK = 0
 STATE_HISTORY_LENGTH, STATE_MOMENTS, STATE_COLOR_HISTORY, STATE_VARIANCE_TEMPORAL, STATE_COLOR_ACC = range(5)
-KERNEL_TEMPORAL, KERNEL_PREPARE, KERNEL_ATROUS, KERNEL_DEBUGVIEW, KERNEL_COPYOUT = 1, 2, 3, 4, 5
+KERNEL_TEMPORAL, KERNEL_PREPARE, KERNEL_ATROUS, KERNEL_DEBUGVIEW, KERNEL_COPYOUT, KERNEL_FUSED = 1, 2, 3, 4, 5, 6
 MAX_LEVELS = 10
 
 # every symbol include/svgf.h declares

@@ -12,7 +12,7 @@ LIB = os.path.join(_HERE, "libsvgf_hip.so")
 ORACLE_DIR = os.path.join(ROOT, "oracle")
 ORACLE_LIB = os.path.join(ORACLE_DIR, "libsvgf_oracle.so")
 
-HIP_SOURCES = ["svgf_api.hip", "svgf_kernels.hip", "svgf_atrous_strip.hip", "svgf_atrous_lane.hip", "svgf_atrous_lattice.hip", "svgf_synth.hip", "svgf_scene.hip", "svgf_display.hip"]
+HIP_SOURCES = ["svgf_api.hip", "svgf_kernels.hip", "svgf_atrous_strip.hip", "svgf_atrous_lane.hip", "svgf_atrous_fused.hip", "svgf_atrous_lattice.hip", "svgf_synth.hip", "svgf_scene.hip", "svgf_display.hip"]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-function"]
 
 
@@ -40,7 +40,7 @@ def hipcc_path() -> str:
 def build_hip(force: bool = False) -> str:
     """Compile the HIP kernels + C ABI for gfx950 into cuda-path-tracer-denoising_amd/libsvgf_hip.so."""
     srcs = [os.path.join(CSRC, s) for s in HIP_SOURCES]
-    deps = srcs + [os.path.join(CSRC, "svgf_kernels.h"), os.path.join(ROOT, "include", "svgf.h")]
+    deps = srcs + [os.path.join(CSRC, h) for h in ("svgf_kernels.h", "svgf_temporal.h", "svgf_atrous_lane_impl.h")] + [os.path.join(ROOT, "include", "svgf.h")]
     if not force and _newer(LIB, deps):
         return LIB
     tmp = LIB + f".tmp{os.getpid()}"

@@ -29,6 +29,16 @@ void denoiseInit(Scene *scene)
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (g_ctx) { svgf_destroy(g_ctx); g_ctx = nullptr; }
+    // The parameter block has grown at its tail between ABI versions (0.2: 72 bytes, 0.3: 80) and svgf_denoise reads all of
+    // the library's version of it: a shim compiled against another svgf.h than the libsvgf_hip.so it is linked with would
+    // hand over a short struct whose tail fields (reproj_position_tol, spatial_variance_frames) are whatever follows it on
+    // the stack.  Refuse loudly instead: no context is created and every denoise() call reports it.
+    if (svgf_params_sizeof() != (int)sizeof(SvgfParams)) {
+        fprintf(stderr, "denoiseInit: svgf.h / libsvgf_hip.so mismatch: sizeof(SvgfParams) is %d in this build of denoise_compat.cpp, "
+                        "%d in the library (version %d.%d); rebuild the shim against the library's include/svgf.h\n",
+                (int)sizeof(SvgfParams), svgf_params_sizeof(), svgf_version() >> 16, svgf_version() & 0xffff);
+        return;
+    }
     const int rc = svgf_create(dev, cam.resolution.x, cam.resolution.y, &g_ctx);
     if (rc != SVGF_OK) fprintf(stderr, "denoiseInit: svgf_create failed (%d): %s\n", rc, svgf_last_error(nullptr));
 }

@@ -16,16 +16,19 @@
 #include "svgf_kernels.h"
 
 #define SVGF_MAX_KERNELS_PER_FRAME (SVGF_MAX_LEVELS + 4)
+// a row of the fused temporal + first-level kernel against a row of the plain lane kernel (measured)
+static const double kFusedRowFactor = 1.5;
 
 struct svgf_ctx {
     int device, W, H;
     size_t n;
-    float4 *cv[4];
-    float *vp[4];          // zero-margined (W+2) x (H+2) copies of cv[k].w: what the step-16/32 levels take their 3x3 variance pre-blur from
+    float4 *cv[3];         // colour + variance planes: history, source, destination of a level (roles rotate)
+    float *vp[3];          // zero-margined (W+2) x (H+2) copies of cv[k].w: what the step-16/32 levels take their 3x3 variance pre-blur from
     unsigned vp_valid;     // bit k: vp[k] holds the variance of cv[k]
     int use_vplane;        // 0 only for A/B measurements (environment SVGF_NO_VARIANCE_PLANE at svgf_create)
     int n_cu;              // compute units of the context's device (launch-geometry cost model of the kernel choice)
     signed char lane_cheaper[8];   // per log2(step): -1 not evaluated yet, 1 the lane kernel's estimate is the lower one
+    signed char fuse_pays;         // -1 not evaluated yet, 1: the fused temporal + first-level kernel is the cheaper way through both
     float *nrm[2];
     int *gid[2];
     float *pos[2];
@@ -36,12 +39,6 @@ struct svgf_ctx {
     int acc;       // cv index the last temporal pass wrote
     int cur;       // mom/hlen index holding the history the next frame reads
     int gcur;      // nrm/gid/pos index holding the previous frame's planes
-    // cross-frame overlap (SvgfParams::inputs_ready): the temporal pass of frame f+1 runs on `side` concurrently with the
-    // a-trous levels of frame f that come after the level feeding the colour history
-    hipStream_t side;
-    hipEvent_t ev_hist, ev_temporal;
-    int ev_hist_valid;
-    unsigned inflight_mask;   // cv planes the previous frame's levels after its history level still write
     float view_prev[16];   // column-major; identity until the first frame (reference src/denoise.cu:15)
     // state capture for tests
     int capture;
@@ -125,8 +122,8 @@ extern "C" int svgf_params_default(SvgfParams *p)
 
 static void free_all(svgf_ctx *c)
 {
-    for (int k = 0; k < 4; k++) if (c->cv[k]) (void)hipFree(c->cv[k]);
-    for (int k = 0; k < 4; k++) if (c->vp[k]) (void)hipFree(c->vp[k]);
+    for (int k = 0; k < 3; k++) if (c->cv[k]) (void)hipFree(c->cv[k]);
+    for (int k = 0; k < 3; k++) if (c->vp[k]) (void)hipFree(c->vp[k]);
     for (int k = 0; k < 2; k++) {
         if (c->nrm[k]) (void)hipFree(c->nrm[k]);
         if (c->gid[k]) (void)hipFree(c->gid[k]);
@@ -135,9 +132,6 @@ static void free_all(svgf_ctx *c)
     }
     for (int k = 0; k < 2; k++) if (c->pos[k]) (void)hipFree(c->pos[k]);
     if (c->albedo) (void)hipFree(c->albedo);
-    if (c->side) (void)hipStreamDestroy(c->side);
-    if (c->ev_hist) (void)hipEventDestroy(c->ev_hist);
-    if (c->ev_temporal) (void)hipEventDestroy(c->ev_temporal);
     if (c->cv_capture) (void)hipFree(c->cv_capture);
     if (c->st_in) (void)hipFree(c->st_in);
     if (c->st_out) (void)hipFree(c->st_out);
@@ -150,8 +144,8 @@ static void free_all(svgf_ctx *c)
 
 static int zero_state(svgf_ctx *c)
 {
-    for (int k = 0; k < 4; k++) if (c->cv[k]) HIPC(c, hipMemset(c->cv[k], 0, c->n * sizeof(float4)));
-    for (int k = 0; k < 4; k++) if (c->vp[k]) HIPC(c, hipMemset(c->vp[k], 0, (size_t)(c->W + 2) * (c->H + 2) * sizeof(float)));
+    for (int k = 0; k < 3; k++) if (c->cv[k]) HIPC(c, hipMemset(c->cv[k], 0, c->n * sizeof(float4)));
+    for (int k = 0; k < 3; k++) if (c->vp[k]) HIPC(c, hipMemset(c->vp[k], 0, (size_t)(c->W + 2) * (c->H + 2) * sizeof(float) + 64));
     c->vp_valid = 0;
     for (int k = 0; k < 2; k++) {
         HIPC(c, hipMemset(c->nrm[k], 0, c->n * 3 * sizeof(float)));
@@ -160,8 +154,9 @@ static int zero_state(svgf_ctx *c)
         HIPC(c, hipMemset(c->hlen[k], 0, c->n * sizeof(int)));
         HIPC(c, hipMemset(c->pos[k], 0, c->n * 3 * sizeof(float)));
     }
-    c->hist = 0; c->acc = 0; c->cur = 0; c->gcur = 0;
-    c->ev_hist_valid = 0; c->inflight_mask = 0;
+    // gcur is deliberately NOT reset: the pointers svgf_planar_gbuffer handed out (planes 1 - gcur) stay the ones the next
+    // frame reads, so planar_gbuffer() -> reset() -> producer -> denoise_planar() works (both plane sets are zero again)
+    c->hist = 0; c->acc = 0; c->cur = 0;
     return SVGF_OK;
 }
 
@@ -193,9 +188,8 @@ extern "C" int svgf_create(int device, int width, int height, svgf_ctx **out)
     c->use_vplane = getenv("SVGF_NO_VARIANCE_PLANE") ? 0 : 1;
     if (hipDeviceGetAttribute(&c->n_cu, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || c->n_cu < 8) c->n_cu = 256;
     memset(c->lane_cheaper, -1, sizeof(c->lane_cheaper));
+    c->fuse_pays = -1;
     bool ok = true;
-    // three colour planes serve the ordered path (history, source, destination); the fourth one, the side stream and its
-    // events belong to the cross-frame overlap and are created when a frame first asks for it (ensure_overlap_resources)
     for (int k = 0; k < 3 && ok; k++) ok = hipMalloc((void **)&c->cv[k], c->n * sizeof(float4)) == hipSuccess;
     // (+64 bytes: the step-16/32 lane kernel reads the variance plane in 16-byte pieces that may end 8 bytes behind the last margin)
     for (int k = 0; k < 3 && ok; k++) ok = hipMalloc((void **)&c->vp[k], (size_t)(width + 2) * (height + 2) * sizeof(float) + 64) == hipSuccess;
@@ -217,31 +211,6 @@ extern "C" int svgf_create(int device, int width, int height, svgf_ctx **out)
         return SVGF_ERR_HIP;
     }
     *out = c;
-    return SVGF_OK;
-}
-
-// cross-frame overlap (SvgfParams::inputs_ready): a fourth colour plane, a high-priority side stream and two events.
-// Created when a frame first asks for it, possibly on a context that has been running ORDERED frames whose kernels are
-// still queued on the caller's stream `s`: the history event is recorded on that stream right away (and the new planes
-// are cleared on it), so that the first temporal pass on the side stream waits for everything the ordered frames enqueued.
-static int ensure_overlap_resources(svgf_ctx *c, hipStream_t s)
-{
-    if (c->side) return SVGF_OK;
-    if (!c->cv[3]) {
-        HIPC(c, hipMalloc((void **)&c->cv[3], c->n * sizeof(float4)));
-        HIPC(c, hipMemsetAsync(c->cv[3], 0, c->n * sizeof(float4), s));
-    }
-    if (!c->vp[3]) {
-        HIPC(c, hipMalloc((void **)&c->vp[3], (size_t)(c->W + 2) * (c->H + 2) * sizeof(float) + 64));
-        HIPC(c, hipMemsetAsync(c->vp[3], 0, (size_t)(c->W + 2) * (c->H + 2) * sizeof(float), s));
-    }
-    if (!c->ev_hist) HIPC(c, hipEventCreateWithFlags(&c->ev_hist, hipEventDisableTiming));
-    if (!c->ev_temporal) HIPC(c, hipEventCreateWithFlags(&c->ev_temporal, hipEventDisableTiming));
-    int lo = 0, hi = 0;   // the side stream carries the short, latency-sensitive temporal pass: highest priority
-    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-    HIPC(c, hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, hi));
-    HIPC(c, hipEventRecord(c->ev_hist, s));
-    c->ev_hist_valid = 1;
     return SVGF_OK;
 }
 
@@ -398,6 +367,22 @@ static bool lane_pays(svgf_ctx *c, const AtrousArgs &a)
     return c->lane_cheaper[l] != 0;
 }
 
+// Temporal pass + first level as ONE kernel (svgf_atrous_fused.hip), or as two?  The fused kernel works on 240-column strips
+// with both y-phases of a strip in one workgroup and pays the same rounds x (rows + 6) launch geometry as the lane kernel; what
+// it saves is the temporal kernel (HBM-bound, 25.6 ns per kilopixel at 1080p) and 56 B/px of traffic between the two.  It runs
+// when its estimate is below the estimate of the level it replaces plus the temporal pass.
+static bool fuse_pays(svgf_ctx *c, const AtrousArgs &a)
+{
+    if (c->fuse_pays < 0) {
+        const double lane = atrous_lane_supported(a) ? atrous_lane_estimate_us(a, c->n_cu) : 1e30;
+        const double strip = atrous_strip_supported(a) ? atrous_strip_estimate_us(a, c->n_cu) : 1e30;
+        const double level = lane < strip ? lane : strip;
+        const double temporal_us = 0.0256e-3 * (double)c->W * (double)c->H;
+        c->fuse_pays = (kFusedRowFactor * atrous_fused_estimate_us(a, c->n_cu) <= level + temporal_us && level < 1e29) ? 1 : 0;
+    }
+    return c->fuse_pays != 0;
+}
+
 // gbuffer_dev == nullptr: the planar path (svgf_denoise_planar) — the current-frame planes nrm/pos/gid[1 - gcur] (and `albedo`)
 // were filled in place by the producer
 static int denoise_frame(svgf_ctx *c, void *out_rgb_dev, const void *in_rgb_dev, const void *gbuffer_dev,
@@ -411,7 +396,7 @@ static int denoise_frame(svgf_ctx *c, void *out_rgb_dev, const void *in_rgb_dev,
         snprintf(c->err, sizeof(c->err), "svgf_denoise: atrous_nlevel %d outside 0..%d", p->atrous_nlevel, SVGF_MAX_LEVELS);
         return SVGF_ERR_INVALID_ARG;
     }
-    if (p->kernel_variant < 0 || p->kernel_variant > 4 || p->kernel_variant == 3) {
+    if (p->kernel_variant < 0 || p->kernel_variant > 6 || p->kernel_variant == 3) {
         snprintf(c->err, sizeof(c->err), p->kernel_variant == 3
                  ? "svgf_denoise: kernel_variant %d (experimental shared-weight kernel) is no longer part of the library, see tools/experiments/"
                  : "svgf_denoise: kernel_variant %d unknown", p->kernel_variant);
@@ -445,83 +430,50 @@ static int denoise_frame(svgf_ctx *c, void *out_rgb_dev, const void *in_rgb_dev,
         c->ev_n[timer.slot] = 0;
     }
 
-    // 1) temporal accumulation, or constant variance (reference :360-371).  Writes a cv plane `acc` that neither holds
-    //    the colour history nor is still written by the previous frame's trailing a-trous levels, and the current-frame
-    //    G-buffer planes.
-    //    Cross-frame overlap: when the caller promises that the inputs are complete at call time (inputs_ready), this
-    //    pass runs on the context's side stream as soon as the level feeding the colour history of the PREVIOUS frame
-    //    is done, i.e. concurrently with that frame's remaining levels.  The temporal pass is HBM-bound and the a-trous
-    //    levels are VALU-bound, so the two kernels share the CUs well.
-    //    Only the temporal pass is worth a second stream: the constant-variance fill of the non-temporal mode is a
-    //    few microseconds, less than the cross-stream event hand-off costs.
-    const bool overlap = (p->inputs_ready != 0) && (p->temporal_enable != 0);
-    if (overlap) { const int rc = ensure_overlap_resources(c, (hipStream_t)stream); if (rc != SVGF_OK) return rc; }
-    const int ncv = c->cv[3] ? 4 : 3;
-    // planes the previous frame's trailing levels still write matter only when this frame's temporal pass may run beside
-    // them (side stream); on the ordered path the stream order protects them
-    const unsigned busy = overlap ? c->inflight_mask : 0u;
-    int acc = -1;
-    for (int k = 0; k < ncv; k++) if (k != c->hist && !((busy >> k) & 1u)) { acc = k; break; }
-    if (acc < 0) { snprintf(c->err, sizeof(c->err), "svgf_denoise: internal error, no free colour plane"); return SVGF_ERR_HIP; }
+    // 1) temporal accumulation, or constant variance (reference :360-371).  Writes a cv plane `acc` that does not hold the
+    //    colour history, and the current-frame G-buffer planes.  When the frame runs the a-trous cascade on the fast path the
+    //    temporal pass is not launched at all: the first level's loader waves accumulate the pixels they stage (fused
+    //    kernel, svgf_atrous_fused.hip) and `acc` stays unwritten unless something other than that level needs it.
+    //    (SvgfParams::inputs_ready, the cross-frame overlap of rounds 1-3, is accepted and ignored: it lost 3-8 % once the
+    //    lane kernel ran all five levels, and the fusion removes the pass it used to hide.)
+    const int old_hist = c->hist;
+    const int acc = (old_hist + 1) % 3;
     const int gnew = 1 - c->gcur;
-    hipStream_t ts = overlap ? c->side : s;
-    if (overlap && c->ev_hist_valid) HIPC(c, hipStreamWaitEvent(c->side, c->ev_hist, 0));
-    {
-        KernelTimer timer_t = timer; timer_t.s = ts;
-        KernelTimer &timer_ref = timer_t;
-#define LAUNCH_T(kind, expr)                                                                         \
-    do {                                                                                             \
-        if (!timer_ref.begin(kind)) { snprintf(c->err, sizeof(c->err), "hipEventRecord failed"); return SVGF_ERR_HIP; } \
-        HIPC(c, (expr));                                                                             \
-        if (!timer_ref.end()) { snprintf(c->err, sizeof(c->err), "hipEventRecord failed"); return SVGF_ERR_HIP; }       \
-    } while (0)
-        if (p->temporal_enable) {
-            TemporalArgs t;
-            t.in_rgb = in; t.gbuf = g; t.cv_hist = c->cv[c->hist]; t.cv_acc = c->cv[acc];
-            t.mom_hist = c->mom[c->cur]; t.mom_acc = c->mom[1 - c->cur];
-            t.hlen = c->hlen[c->cur]; t.hlen_upd = c->hlen[1 - c->cur];
-            t.nrm_prev = c->nrm[c->gcur]; t.gid_prev = c->gid[c->gcur];
-            t.nrm_cur = c->nrm[gnew]; t.gid_cur = c->gid[gnew]; t.pos_cur = c->pos[gnew];
-            memcpy(t.M, c->view_prev, sizeof(t.M));
-            t.W = c->W; t.H = c->H; t.color_alpha_min = p->color_alpha; t.moment_alpha_min = p->moment_alpha;
-            t.reproj_sx = p->reproj_scale[0]; t.reproj_sy = p->reproj_scale[1];
-            t.pos_prev = c->pos[c->gcur]; t.pos_tol = p->reproj_position_tol;
-            LAUNCH_T(SVGF_KERNEL_TEMPORAL, launch_temporal(t, ts, overlap && c->ev_hist_valid));
-            if (p->spatial_variance_frames > 0)      // f4 extension: spatial variance estimate for short histories (its own profiling slot, same kind)
-                LAUNCH_T(SVGF_KERNEL_TEMPORAL, launch_spatial_variance(c->cv[acc], c->mom[1 - c->cur], c->hlen[1 - c->cur], c->nrm[gnew], c->gid[gnew],
-                                                                       c->W, c->H, p->spatial_variance_frames, ts));
-        } else {
-            LAUNCH_T(SVGF_KERNEL_PREPARE, launch_prepare(in, g, c->cv[acc], c->nrm[gnew], c->gid[gnew], c->pos[gnew], c->W, c->H, ts));
+    const bool cascade = !(p->right_view_option == 1 || p->right_view_option == 2 || p->atrous_nlevel == 0 || !p->spatial_enable);
+    TemporalArgs t;
+    memset(&t, 0, sizeof(t));
+    bool fused = false;
+    if (p->temporal_enable) {
+        t.in_rgb = in; t.gbuf = g; t.cv_hist = c->cv[c->hist]; t.cv_acc = c->cv[acc];
+        t.mom_hist = c->mom[c->cur]; t.mom_acc = c->mom[1 - c->cur];
+        t.hlen = c->hlen[c->cur]; t.hlen_upd = c->hlen[1 - c->cur];
+        t.nrm_prev = c->nrm[c->gcur]; t.gid_prev = c->gid[c->gcur];
+        t.nrm_cur = c->nrm[gnew]; t.gid_cur = c->gid[gnew]; t.pos_cur = c->pos[gnew];
+        memcpy(t.M, c->view_prev, sizeof(t.M));
+        t.W = c->W; t.H = c->H; t.color_alpha_min = p->color_alpha; t.moment_alpha_min = p->moment_alpha;
+        t.reproj_sx = p->reproj_scale[0]; t.reproj_sy = p->reproj_scale[1];
+        t.pos_prev = c->pos[c->gcur]; t.pos_tol = p->reproj_position_tol;
+        if (cascade && (p->kernel_variant == 0 || p->kernel_variant == 6) && !p->paper_steps && p->spatial_variance_frames <= 0) {
+            AtrousArgs probe;
+            memset(&probe, 0, sizeof(probe));
+            probe.W = c->W; probe.H = c->H; probe.step = 2;
+            fused = atrous_fused_supported(probe, t) && (p->kernel_variant == 6 || fuse_pays(c, probe));
         }
-        c->vp_valid &= ~(1u << acc);     // the temporal / prepare pass writes no variance plane: the first level gathers cv.w
-#undef LAUNCH_T
+        if (!fused) {
+            LAUNCH(SVGF_KERNEL_TEMPORAL, launch_temporal(t, s, false));
+            if (p->spatial_variance_frames > 0)      // f4 extension: spatial variance estimate for short histories (its own profiling slot, same kind)
+                LAUNCH(SVGF_KERNEL_TEMPORAL, launch_spatial_variance(c->cv[acc], c->mom[1 - c->cur], c->hlen[1 - c->cur], c->nrm[gnew], c->gid[gnew],
+                                                                     c->W, c->H, p->spatial_variance_frames, s));
+        }
+    } else {
+        LAUNCH(SVGF_KERNEL_PREPARE, launch_prepare(in, g, c->cv[acc], c->nrm[gnew], c->gid[gnew], c->pos[gnew], c->W, c->H, s));
     }
+    c->vp_valid &= ~(1u << acc);     // the temporal / prepare pass writes no variance plane: the first level gathers cv.w
     c->acc = acc;
     c->hist = acc;                                   // color_history <- color_acc / input (:366,370)
-    if (c->capture) HIPC(c, hipMemcpyAsync(c->cv_capture, c->cv[acc], c->n * sizeof(float4), hipMemcpyDeviceToDevice, ts));
-    if (overlap) {
-        HIPC(c, hipEventRecord(c->ev_temporal, c->side));
-        HIPC(c, hipStreamWaitEvent(s, c->ev_temporal, 0));
-    }
-    c->inflight_mask = 0;
-    bool hist_final = false;         // has the kernel that produces next frame's colour history been enqueued?
-    auto mark_hist_final = [&]() -> bool {
-        hist_final = true;
-        if (!c->ev_hist) return true;                 // overlap never used on this context: nobody waits for the event
-        if (hipEventRecord(c->ev_hist, s) != hipSuccess) return false;
-        c->ev_hist_valid = 1;
-        return true;
-    };
+    if (c->capture && !fused) HIPC(c, hipMemcpyAsync(c->cv_capture, c->cv[acc], c->n * sizeof(float4), hipMemcpyDeviceToDevice, s));
 
     // 2) debug views, pass-through or the a-trous cascade (:373-394)
-    const bool cascade = !(p->right_view_option == 1 || p->right_view_option == 2 || p->atrous_nlevel == 0 || !p->spatial_enable);
-    // When no a-trous level feeds the history, the history (colour, moments, lengths) is final after the temporal pass —
-    // but the next frame's temporal pass, which waits on ev_hist only, REWRITES the planes the debug / copy kernels below
-    // read (hlen[cur] becomes next frame's hlen_upd): the event is recorded behind those kernels, not in front of them.
-    const bool hist_final_early = !cascade || p->history_level < 1 || p->history_level > p->atrous_nlevel;
-    if (hist_final_early && cascade) {
-        if (!mark_hist_final()) { snprintf(c->err, sizeof(c->err), "hipEventRecord failed"); return SVGF_ERR_HIP; }
-    }
     if (p->right_view_option == 1) {
         LAUNCH(SVGF_KERNEL_DEBUGVIEW, launch_debug_hlen(c->hlen[c->cur], out, n, 100.0f, s));   // pre-update lengths (:374)
     } else if (p->right_view_option == 2) {
@@ -533,9 +485,11 @@ static int denoise_frame(svgf_ctx *c, void *out_rgb_dev, const void *in_rgb_dev,
         for (int level = 1; level <= p->atrous_nlevel; level++) {
             const bool last = (level == p->atrous_nlevel);
             const bool keep = (level == p->history_level);      // this level's output becomes the colour history (:391)
+            const bool fuse_here = fused && level == 1;
             int dst = -1;
             if (!last || keep) {
-                for (int k = 0; k < ncv; k++) if (k != src && k != c->hist) { dst = k; break; }
+                // (the fused level reads the OLD colour history while it writes: its destination is the third plane)
+                for (int k = 0; k < 3; k++) if (k != src && k != c->hist && !(fuse_here && k == old_hist)) { dst = k; break; }
             }
             AtrousArgs a;
             a.src = c->cv[src]; a.dst = dst >= 0 ? c->cv[dst] : nullptr; a.out_rgb = last ? out : nullptr;
@@ -554,8 +508,10 @@ static int denoise_frame(svgf_ctx *c, void *out_rgb_dev, const void *in_rgb_dev,
                 strip = atrous_strip_supported(a);
                 lattice = !strip && p->kernel_variant != 2 && atrous_lattice_supported(a);     // steps 64, 128, ...
             }
-            enum { K_LANE, K_STRIP, K_LATTICE, K_GATHER } which;
-            if (strip && atrous_lane_supported(a) && (p->kernel_variant == 4 || (p->kernel_variant == 0 && lane_pays(c, a)))) which = K_LANE;
+            enum { K_FUSED, K_LANE, K_LANE2Y, K_STRIP, K_LATTICE, K_GATHER } which;
+            if (fuse_here) which = K_FUSED;
+            else if (strip && a.step == 2 && p->kernel_variant == 5 && atrous_lane_supported(a)) which = K_LANE2Y;
+            else if (strip && atrous_lane_supported(a) && (p->kernel_variant >= 4 || (p->kernel_variant == 0 && lane_pays(c, a)))) which = K_LANE;
             else if (strip) which = K_STRIP;
             else if (lattice) which = K_LATTICE;
             else which = K_GATHER;
@@ -572,22 +528,22 @@ static int denoise_frame(svgf_ctx *c, void *out_rgb_dev, const void *in_rgb_dev,
             }
             if (dst >= 0) { if (a.var_dst) c->vp_valid |= 1u << dst; else c->vp_valid &= ~(1u << dst); }
             switch (which) {
+            case K_FUSED:
+                // the accumulated plane itself is only written when something besides this level reads it: a later frame (the
+                // history is not this level's output) or a test (svgf_set_capture)
+                t.cv_acc = (!keep || c->capture) ? c->cv[acc] : nullptr;
+                LAUNCH(SVGF_KERNEL_FUSED, launch_atrous_fused(a, t, s));
+                if (c->capture) HIPC(c, hipMemcpyAsync(c->cv_capture, c->cv[acc], c->n * sizeof(float4), hipMemcpyDeviceToDevice, s));
+                break;
             case K_LANE:    LAUNCH(SVGF_KERNEL_ATROUS, launch_atrous_lane(a, s)); break;     // steps 2 .. 32: symmetric terms evaluated once
+            case K_LANE2Y:  LAUNCH(SVGF_KERNEL_ATROUS, launch_atrous_lane_2y(a, s)); break;  // A/B partner of the fused kernel's geometry
             case K_STRIP:   LAUNCH(SVGF_KERNEL_ATROUS, launch_atrous_strip(a, s)); break;
             case K_LATTICE: LAUNCH(SVGF_KERNEL_ATROUS, launch_atrous_lattice(a, s)); break;
             default:        LAUNCH(SVGF_KERNEL_ATROUS, launch_atrous_gather(a, s)); break;
             }
-            if (hist_final && dst >= 0) c->inflight_mask |= 1u << dst;   // written after the history is final
-            if (keep) {
-                c->hist = dst;
-                if (!mark_hist_final()) { snprintf(c->err, sizeof(c->err), "hipEventRecord failed"); return SVGF_ERR_HIP; }
-            }
+            if (keep) c->hist = dst;
             src = dst;
         }
-    }
-
-    if (!cascade) {
-        if (!mark_hist_final()) { snprintf(c->err, sizeof(c->err), "hipEventRecord failed"); return SVGF_ERR_HIP; }
     }
 
     // 3) history rotation (:396-399): planes swap roles instead of being copied

@@ -1,0 +1,43 @@
+// svgf_atrous_fused.hip — the temporal pass fused into the first a-trous level (round 4).
+//
+// The temporal pass (reference BackProjection, src/denoise.cu:185-317, launched :362-367) is HBM- and latency-bound with the
+// VALU mostly idle; the a-trous level that follows it (src/denoise.cu:77-170, first iteration of the loop :386-392) is
+// instruction-issue-bound with HBM half idle, and the level reads back what the pass has just written (16 B/px each way) plus
+// the planes it split the G-buffer into (24 B/px).  Here the two share ONE sweep over the frame: the loader waves of the
+// lane-marching kernel (svgf_atrous_lane_impl.h, FUSED) accumulate the pixels they stage instead of loading them — the
+// arithmetic is k_temporal's, function for function (svgf_temporal.h) — so the accumulated colour + variance exists only in the
+// LDS ring, and only the workgroup that OWNS a pixel writes its moments, history length and split G-buffer planes.
+// The 3x3 variance pre-blur of the level needs the accumulated variance of rows y-1 / y+1: a workgroup therefore holds BOTH
+// y-phases of a 240-column strip (LOG2Y = 1), which makes those rows ring rows.  Halo rows and columns are accumulated by
+// more than one workgroup (1.27x at 1080p); nothing is communicated between workgroups.
+//
+// Also here: the same two-y-phase geometry WITHOUT the fusion (kernel_variant 5), the A/B partner that separates what the
+// geometry costs from what the fusion brings.
+#include "svgf_atrous_lane_impl.h"
+
+bool atrous_fused_supported(const AtrousArgs &a, const TemporalArgs &t)
+{
+    if (a.step != 2) return false;                                   // the reference's first level (src/denoise.cu:98,386)
+    if ((long long)a.W * a.H * 16 >= (1LL << 32)) return false;
+    if (t.pos_tol > 0.0f) return false;                              // f4 extension, k_temporal only
+    return true;
+}
+
+double atrous_fused_estimate_us(const AtrousArgs &a, int n_cu)
+{
+    int L = 0;
+    return 1.857 * (double)lane_segment_search(lane_strip_count(a.W, 2, 2), 1, (a.H + 1) / 2, n_cu, &L);
+}
+
+hipError_t launch_atrous_fused(const AtrousArgs &a, const TemporalArgs &t, hipStream_t s)
+{
+    if (a.step != 2) return hipErrorInvalidValue;
+    return a.dst ? launch_lane_cfg<1, true, 1, 1, true>(a, s, &t) : launch_lane_cfg<1, false, 1, 1, true>(a, s, &t);
+}
+
+// step 2 with both y-phases in one workgroup, not fused (reads the accumulated plane like every other level)
+hipError_t launch_atrous_lane_2y(const AtrousArgs &a, hipStream_t s)
+{
+    if (a.step != 2) return hipErrorInvalidValue;
+    return a.dst ? launch_lane_cfg<1, true, 1, 1, false>(a, s) : launch_lane_cfg<1, false, 1, 1, false>(a, s);
+}

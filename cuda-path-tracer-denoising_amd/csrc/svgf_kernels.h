@@ -102,6 +102,12 @@ double     atrous_strip_estimate_us(const AtrousArgs &a, int n_cu);   // launch-
 hipError_t launch_atrous_lane(const AtrousArgs &a, hipStream_t s);     // lane-marching kernel, symmetric terms shared by DPP (steps 1 .. 32)
 bool       atrous_lane_supported(const AtrousArgs &a);
 double     atrous_lane_estimate_us(const AtrousArgs &a, int n_cu);
+// temporal pass fused into the first level (step 2): the lane kernel's loader waves accumulate the pixels they stage
+// (svgf_atrous_fused.hip).  t.cv_acc may be null: the accumulated colour then exists only in LDS.
+hipError_t launch_atrous_fused(const AtrousArgs &a, const TemporalArgs &t, hipStream_t s);
+bool       atrous_fused_supported(const AtrousArgs &a, const TemporalArgs &t);
+double     atrous_fused_estimate_us(const AtrousArgs &a, int n_cu);
+hipError_t launch_atrous_lane_2y(const AtrousArgs &a, hipStream_t s);  // step 2, both y-phases per workgroup, not fused (A/B)
 hipError_t launch_atrous_lattice(const AtrousArgs &a, hipStream_t s);  // lattice sub-images in LDS (steps >= 64)
 bool       atrous_lattice_supported(const AtrousArgs &a);
 // albedo * ialbedo of the last level's re-modulation (:166-168), from the AoS texel or from the planar path's plane

@@ -5,6 +5,7 @@
 // oracle to the last ulp except inside expf.  They are the correctness anchors; the bandwidth-shaped a-trous
 // kernel lives in svgf_atrous_strip.hip.
 #include "svgf_kernels.h"
+#include "svgf_temporal.h"
 
 #define SVGF_BLOCK 256
 
@@ -14,24 +15,9 @@ static inline int div_up(long long a, int b) { return (int)((a + b - 1) / b); }
 // helpers
 // ----------------------------------------------------------------------------------------------------
 
-// luminance with the reference's double promotion (src/denoise.cu:121,138,196)
-__device__ __forceinline__ float lum_strict(float r, float g, float b)
-{
-#pragma clang fp contract(off)
-    double l = 0.2126 * (double)r + 0.7152 * (double)g;
-    l = l + 0.0722 * (double)b;
-    return (float)l;
-}
-
-// glm::distance(vec3,vec3): sqrt((dx*dx + dy*dy) + dz*dz)
-__device__ __forceinline__ float dist3_strict(float ax, float ay, float az, float bx, float by, float bz)
-{
-#pragma clang fp contract(off)
-    float dx = bx - ax, dy = by - ay, dz = bz - az;
-    float s = dx * dx + dy * dy;
-    s = s + dz * dz;
-    return sqrtf(s);
-}
+// luminance / distance in the reference's operation order: svgf_temporal.h (shared with the fused kernel)
+__device__ __forceinline__ float lum_strict(float r, float g, float b) { return svgf_lum_strict(r, g, b); }
+__device__ __forceinline__ float dist3_strict(float ax, float ay, float az, float bx, float by, float bz) { return svgf_dist3_strict(ax, ay, az, bx, by, bz); }
 
 // ----------------------------------------------------------------------------------------------------
 // temporal accumulation  (reference BackProjection src/denoise.cu:185-317, isReprjValid :172-182)
@@ -41,14 +27,10 @@ __device__ __forceinline__ float dist3_strict(float ax, float ay, float az, floa
 
 __device__ __forceinline__ int reproj_valid(const TemporalArgs &a, float qx, float qy, int gid, float nx, float ny, float nz)
 {
-    if (!(qx == qx) || !(qy == qy)) return -1;                      // NaN coordinate: defined as invalid
-    if (qx < 0.0f || qx >= (float)a.W || qy < 0.0f || qy >= (float)a.H) return -1;
-    int q = (int)qx + (int)qy * a.W;
-    int gq = a.gid_prev[q];
-    if (gq == -1 || gq != gid) return -1;
+    const int q = svgf_tap_index(a, qx, qy);                          // bounds (:173-176); NaN coordinate: defined as invalid
+    if (q < 0) return -1;
     const float *n = a.nrm_prev + 3 * (size_t)q;
-    if (dist3_strict(n[0], n[1], n[2], nx, ny, nz) > 1e-1f) return -1;
-    return q;
+    return svgf_tap_consistent(a.gid_prev[q], n[0], n[1], n[2], gid, nx, ny, nz) ? q : -1;
 }
 
 // SvgfParams::reproj_position_tol (f4 extension): the tap's previous-frame world position must lie within tol of the
@@ -88,24 +70,13 @@ __global__ __launch_bounds__(BLOCK) void k_temporal(TemporalArgs a)
     const float lum = lum_strict(cr, cg, cb);
     const int N = a.hlen[p];
 
+    bool valid = false;
+    SvgfHistSum hs = { 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f };
     if (N > 0 && gid != -1) {
-        // previous-frame view space; glm mat4*vec4 association (m0 v0 + m1 v1) + (m2 v2 + m3 v3)
-        float vs[3];
-#pragma unroll
-        for (int r = 0; r < 3; r++) {
-            float a0 = a.M[0 * 4 + r] * px + a.M[1 * 4 + r] * py;
-            float a1 = a.M[2 * 4 + r] * pz + a.M[3 * 4 + r] * 1.0f;
-            vs[r] = a0 + a1;
-        }
-        float clipx = vs[0] / vs[2], clipy = vs[1] / vs[2];          // no tan(fov), no aspect (:202-203)
-        if (a.reproj_sx > 0.0f) clipx = clipx / a.reproj_sx;          // f4 extension: exact for any fov / aspect
-        if (a.reproj_sy > 0.0f) clipy = clipy / a.reproj_sy;
-        float ndcx = -clipx * 0.5f + 0.5f, ndcy = -clipy * 0.5f + 0.5f;
-        float prevx = ndcx * (float)a.W - 0.5f, prevy = ndcy * (float)a.H - 0.5f;
-        float fx = floorf(prevx), fy = floorf(prevy);
-        float fracx = prevx - fx, fracy = prevy - fy;
+        const SvgfReproj rp = svgf_reproject(a, px, py, pz);          // previous-frame pixel coordinate (:198-209)
+        const float fx = rp.fx, fy = rp.fy;
 
-        bool valid = (fx >= 0.0f && fy >= 0.0f && fx < (float)a.W && fy < (float)a.H);
+        valid = (fx >= 0.0f && fy >= 0.0f && fx < (float)a.W && fy < (float)a.H);
         int q4[4];
 #pragma unroll
         for (int k = 0; k < 4; k++) {
@@ -113,23 +84,19 @@ __global__ __launch_bounds__(BLOCK) void k_temporal(TemporalArgs a)
             valid = valid && (q4[k] >= 0);
         }
 
-        float pc0 = 0.0f, pc1 = 0.0f, pc2 = 0.0f, pm0 = 0.0f, pm1 = 0.0f, plen = 0.0f;
         if (valid) {                                                  // bilinear (:234-259)
-            float w[4] = { (1 - fracx) * (1 - fracy), fracx * (1 - fracy), (1 - fracx) * fracy, fracx * fracy };
+            float w[4];
+            svgf_bilinear_weights(rp.fracx, rp.fracy, w);
             float sumw = 0.0f;
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 const int q = q4[k];
                 const float4 ch = a.cv_hist[q];
                 const float2 mh = a.mom_hist[q];
-                pc0 += w[k] * ch.x; pc1 += w[k] * ch.y; pc2 += w[k] * ch.z;
-                pm0 += w[k] * mh.x; pm1 += w[k] * mh.y;
-                plen += w[k] * (float)a.hlen[q];
+                svgf_hist_add_weighted(hs, w[k], ch.x, ch.y, ch.z, mh.x, mh.y, a.hlen[q]);
                 sumw += w[k];
             }
-            if ((double)sumw >= 0.01) {
-                pc0 /= sumw; pc1 /= sumw; pc2 /= sumw; pm0 /= sumw; pm1 /= sumw; plen /= sumw;
-            }
+            if ((double)sumw >= 0.01) svgf_hist_div(hs, sumw);
         } else {                                                      // 3x3 box around floor (:262-286)
             float cnt = 0.0f;
             for (int yy = -1; yy <= 1; yy++)
@@ -140,34 +107,20 @@ __global__ __launch_bounds__(BLOCK) void k_temporal(TemporalArgs a)
                     if (q >= 0) {
                         const float4 ch = a.cv_hist[q];
                         const float2 mh = a.mom_hist[q];
-                        pc0 += ch.x; pc1 += ch.y; pc2 += ch.z;
-                        pm0 += mh.x; pm1 += mh.y;
-                        plen += (float)a.hlen[q];
+                        svgf_hist_add(hs, ch.x, ch.y, ch.z, mh.x, mh.y, a.hlen[q]);
                         cnt += 1.0f;
                     }
                 }
             if (cnt > 0.0f) {
-                pc0 /= cnt; pc1 /= cnt; pc2 /= cnt; pm0 /= cnt; pm1 /= cnt; plen /= cnt;
+                svgf_hist_div(hs, cnt);
                 valid = true;
             }
         }
-
-        if (valid) {
-            const float ca = fmaxf(1.0f / (float)(N + 1), a.color_alpha_min);   // alpha on the current side (:297)
-            const float ma = fmaxf(1.0f / (float)(N + 1), a.moment_alpha_min);  // alpha on the history side (:300-301)
-            a.hlen_upd[p] = (int)plen + 1;
-            const float m1 = ma * pm0 + (1.0f - ma) * lum;
-            const float m2 = ma * pm1 + ((1.0f - ma) * lum) * lum;
-            a.mom_acc[p] = make_float2(m1, m2);
-            const float v = m2 - m1 * m1;
-            a.cv_acc[p] = make_float4(cr * ca + pc0 * (1.0f - ca), cg * ca + pc1 * (1.0f - ca),
-                                      cb * ca + pc2 * (1.0f - ca), v > 0.0f ? v : 0.0f);
-            return;
-        }
     }
-    a.hlen_upd[p] = 1;                                                // no usable history (:311-315)
-    a.mom_acc[p] = make_float2(lum, lum * lum);
-    a.cv_acc[p] = make_float4(cr, cg, cb, 100.0f);
+    const SvgfTemporalOut o = svgf_temporal_blend(a, cr, cg, cb, lum, N, valid, hs);
+    a.hlen_upd[p] = o.hlen;
+    a.mom_acc[p] = o.mom;
+    a.cv_acc[p] = o.cv;
 }
 
 hipError_t launch_temporal(const TemporalArgs &a, hipStream_t s, bool single_wave_blocks)

@@ -32,7 +32,7 @@ extern "C" {
 #endif
 
 #define SVGF_VERSION_MAJOR 0
-#define SVGF_VERSION_MINOR 5
+#define SVGF_VERSION_MINOR 6
 
 /* ---- error codes (every entry point returns one of these; the library never exits) ---- */
 #define SVGF_OK                 0
@@ -87,10 +87,17 @@ typedef struct SvgfParams {
                                  2 LDS strip kernel for every step 2-32 (error if a step is unsupported, raised before
                                  anything is enqueued), 3 retired (was an experimental shared-weight kernel, now under
                                  tools/experiments/; SVGF_ERR_INVALID_ARG), 4 lane-marching kernel wherever it is supported (steps
-                                 2-32) whatever the image width, strip / lattice for the rest */
-    int   inputs_ready;       /* 1: in_rgb/gbuffer are complete when svgf_denoise is CALLED (no producer still pending on
-                                 `stream`).  Lets the temporal pass of this frame run on an internal stream concurrently
-                                 with the previous frame's trailing a-trous levels.  0: everything is ordered on `stream`. */
+                                 2-32) whatever the image width, strip / lattice for the rest; the temporal pass is its own
+                                 kernel,
+                                 5 as 4 with the step-2 level on the two-y-phase geometry of the fused kernel, not fused (A/B),
+                                 6 as 4 with the temporal pass fused into the first level on every frame that can be fused
+                                 (temporal and spatial on, no debug view, reference steps, no reproj_position_tol /
+                                 spatial_variance_frames), whatever the cost model says.
+                                 0 fuses where 6 would and the launch-geometry cost model says it pays (ABI 0.6) */
+    int   inputs_ready;       /* accepted and IGNORED since ABI 0.6 (everything is ordered on `stream`).  Rounds 1-3: 1 let the
+                                 temporal pass of this frame run on an internal stream beside the previous frame's trailing
+                                 a-trous levels; it lost 3-8 % once the lane kernel ran every level, and the fused first level
+                                 removes the pass it hid.  The field keeps its place so that the struct layout is unchanged. */
     float reproj_scale[2];    /* "next" row f4, paper-faithful reprojection: if > 0, the previous-frame clip
                                  coordinate is divided by it before the ndc mapping: (tan(FOVY) * W / H, tan(FOVY)) =
                                  (pixelLength.x * W / 2, pixelLength.y * H / 2) makes the reprojection exact for any field
@@ -181,6 +188,7 @@ int svgf_set_capture(svgf_ctx *ctx, int on);
 #define SVGF_KERNEL_ATROUS     3
 #define SVGF_KERNEL_DEBUGVIEW  4
 #define SVGF_KERNEL_COPYOUT    5
+#define SVGF_KERNEL_FUSED      6   /* temporal pass + first a-trous level in one launch (ABI 0.6) */
 /* svgf_profile_stride(ctx, k): bracket only every k-th frame (k >= 1, default 1); the event records lengthen the gaps
  * between kernels by a few microseconds, so a throughput run samples a subset of its frames. */
 int svgf_profile_enable(svgf_ctx *ctx, int nframes);

@@ -97,7 +97,7 @@ def test_hip_matches_oracle_with_f4_options(pkg, orc, W, H, moving, tol, K):
         ref = o.denoise(c, g, cam, params)
         assert np.array_equal(d.read_state(0), o.read_state(0)), f"history length, frame {f}"
         assert relerr(d.read_state(1), o.read_state(1)).max() <= 1e-5, f"moments, frame {f}"
-        assert relerr(d.read_state(3), o.read_state(3)).max() <= 2e-4 * (f + 1), f"variance after the temporal pass, frame {f}"
+        assert relerr(d.read_state(3), o.read_state(3)).max() <= 2e-4, f"variance after the temporal pass, frame {f}"      # flat: no growth allowance
         assert relerr(got, ref).max() <= 1e-4, f"frame {f}: {relerr(got, ref).max():.3e}"
     d.free(); o.free()
 

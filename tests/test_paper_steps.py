@@ -46,7 +46,7 @@ def test_hip_paper_steps_match_oracle(pkg, orc, size, variant):
         got = d.denoise_host(c, g, cam, p)
         ref = o.denoise(c, g, cam, p)
         e = relerr(got, ref)
-        assert e.max() <= 1e-5 * 4 * (f + 1), f"{W}x{H} variant {variant} frame {f}: {e.max():.3e}"
+        assert e.max() <= 1e-5 * 4, f"{W}x{H} variant {variant} frame {f}: {e.max():.3e}"      # flat: no growth allowance
         assert np.array_equal(d.read_state(0), o.read_state(0))
     d.free(); o.free()
 

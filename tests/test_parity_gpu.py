@@ -44,16 +44,19 @@ def native_loaded(pkg):
     assert lib.svgf_version() > 0
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 4])
+@pytest.mark.parametrize("variant", [0, 1, 2, 4, 5, 6])
 @pytest.mark.parametrize("name", CASES)
 def test_hip_matches_reference_goldens(pkg, name, variant):
+    """variant 0: the library's choice (fused temporal + first level where its cost model says so), 1 gather, 2 strip,
+    4 lane kernels with the temporal pass on its own, 5 the fused kernel's two-y-phase geometry without the fusion,
+    6 fused on every frame that can be."""
     z, runs = load_golden(name)
     W, H = int(z["W"]), int(z["H"])
     for tag in runs:
         nl = int(z[f"call_params_{tag}"][0][8])
         if variant == 2 and nl > 5:
             continue                                   # steps 64,128 are served by the gather kernel
-        if variant == 4 and name.startswith("temporal_"):
+        if variant >= 4 and name.startswith("temporal_"):
             continue                                   # no a-trous level runs: same as variant 0
         e = Engine(pkg, W, H, variant)
         got = replay(pkg, e, z, tag)
@@ -158,8 +161,8 @@ def test_levels_6_and_7_use_lattice_kernel_and_match_oracle(pkg, orc, size):
         p.kernel_variant = 0
         got = d.denoise_host(c, g, cam, p)
         e = relerr(got, ref)
-        assert e.max() <= TOL_STRIP * 4 * (f + 1), f"{W}x{H} frame {f}: {e.max():.3e}"
-        assert relerr(d.read_state(2), o.read_state(2)).max() <= TOL_STRIP * 4 * (f + 1), "colour history (level 6/7 output)"
+        assert e.max() <= TOL_STRIP * 4, f"{W}x{H} frame {f}: {e.max():.3e}"      # flat: no growth allowance along the sequence
+        assert relerr(d.read_state(2), o.read_state(2)).max() <= TOL_STRIP * 4, "colour history (level 6/7 output)"
     d.free(); o.free()
     # the same frame through the lattice kernel and through the strict gather kernel
     c, g, cam = pkg.synth.render_frame(W, H, 0, seed=43, moving=False)

@@ -1,0 +1,11 @@
+#!/bin/bash
+# round 4: fused kernel v2 (batched 3x3 fallback): parity subset, timing, then the in-kernel timeline of the fused launch
+O=gpurun_out/r04_fused2; mkdir -p $O
+timeout 900 python -m pytest tests/test_fused_gpu.py -x -q 2>&1 | tail -5 > $O/test_fused.txt
+for v in 6 4; do timeout 300 python tools/probe.py --variants $v --reps 200 > $O/probe_v$v.log 2>&1; done
+SVGF_EXTRA_HIPCC_FLAGS="-DSVGF_LANE_TIMELINE" python -c "
+import sys
+sys.path.insert(0,'.')
+import __graft_entry__ as g
+pkg=g.load_package(); pkg.build.build_hip(force=True)" 2>&1 | grep -v amdgpu.ids | tail -2
+for b in 40 200; do SVGF_LANE_DBG=$b SVGF_LANE_DBG_SKIP=5 timeout 300 python tools/probe.py --variants 6 --frames 3 2>&1 | grep -E "lane dbg|prologue|it +[0-9]+:" | head -120; done > $O/timeline_fused.log 2>&1

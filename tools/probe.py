@@ -14,9 +14,11 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
 import __graft_entry__ as ge  # noqa: E402
+import telemetry  # noqa: E402
 
-KIND = {1: "temporal", 2: "prepare", 3: "atrous", 4: "debug", 5: "copyout"}
+KIND = {1: "temporal", 2: "prepare", 3: "atrous", 4: "debug", 5: "copyout", 6: "fused"}
 
 
 def main():
@@ -28,6 +30,7 @@ def main():
     ap.add_argument("--check", action="store_true", help="compare outputs of the variants frame by frame")
     ap.add_argument("--overlap", type=int, default=0, help="SvgfParams.inputs_ready")
     ap.add_argument("--blur", type=int, default=1, help="SvgfParams.blur_variance")
+    ap.add_argument("--reps", type=int, default=20, help="frames of the back-to-back wall-time loop (no per-kernel events)")
     a = ap.parse_args()
     import torch
     pkg = ge.load_package()
@@ -55,12 +58,14 @@ def main():
         d.profile_enable(0)
         torch.cuda.synchronize()
         e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
-        e0.record()
-        reps = 20
-        for f in range(reps):
-            d.denoise(out, d_in[f % nsrc], d_g[f % nsrc], cam[f % nsrc], p)
-        e1.record(); torch.cuda.synchronize()
+        reps = a.reps
+        with telemetry.Sampler(0) as tm:
+            e0.record()
+            for f in range(reps):
+                d.denoise(out, d_in[f % nsrc], d_g[f % nsrc], cam[f % nsrc], p)
+            e1.record(); torch.cuda.synchronize()
         frame_ms = e0.elapsed_time(e1) / reps
+        tms = tm.summary()
         d.profile_enable(a.frames)
         for f in range(a.frames):
             d.denoise(out, d_in[f % nsrc], d_g[f % nsrc], cam[f % nsrc], p)
@@ -70,11 +75,15 @@ def main():
         nk = len(steady[0])
         med = [float(np.median([r[k][1] for r in steady])) for k in range(nk)]
         kinds = [steady[0][k][0] for k in range(nk)]
-        print(f"variant {v}: frame wall {frame_ms*1e3:.1f} us = {n/frame_ms/1e3:.1f} Mpix/s ; sum of kernels {sum(med)*1e3:.1f} us")
+        print(f"variant {v}: frame wall {frame_ms*1e3:.1f} us = {n/frame_ms/1e3:.1f} Mpix/s ({reps} frames back to back); sum of kernels {sum(med)*1e3:.1f} us")
+        print(f"   telemetry during the wall-time loop: sclk {tms['sclk_mhz']} MHz, power {tms['power_w']} W, temp {tms['temp_c']} C ({tms['n']} samples, {tms['source']})")
         lvl = 0
         for k in range(nk):
             name = KIND[kinds[k]]
             extra = ""
+            if kinds[k] == 6:
+                lvl += 1
+                extra = f" step {1 << lvl:3d}  (temporal pass + level {lvl})"
             if kinds[k] == 3:
                 lvl += 1
                 gbs = 56.0 * n / (med[k] * 1e-3) / 1e9
