@@ -175,9 +175,13 @@ def main():
     os.environ.setdefault("OMP_PROC_BIND", "spread")     # one thread per core, spread over the CCDs: the oracle lives in L3 (close: 5.2, spread: 8.7 Mpix/s at 16 threads)
 
     import torch
+    # SVGF_BENCH_SHARE_DEVICE=1 (tests only): every rank uses device 0 and the ranks rendezvous over gloo — N processes with N
+    # contexts on ONE GPU.  It exercises everything of an N-GPU run that does not need N GPUs (the launcher below, one context per
+    # process, barrier + MAX-time / SUM-pixels reduction, the single JSON line); its throughput figure means nothing.
+    share_device = bool(os.environ.get("SVGF_BENCH_SHARE_DEVICE"))
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # plain `python bench.py --gpus N`: become the launcher — one process per GPU, same rendezvous torchrun would set up
-        if not torch.cuda.is_available() or torch.cuda.device_count() < a.gpus:
+        if not torch.cuda.is_available() or (torch.cuda.device_count() < a.gpus and not share_device):
             raise SystemExit(f"bench.py --gpus {a.gpus}: only {torch.cuda.device_count() if torch.cuda.is_available() else 0} GPU(s) visible")
         import socket
         import subprocess
@@ -192,7 +196,7 @@ def main():
         rcs = [p.wait() for p in procs]
         raise SystemExit(max(rcs))
     rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_rank = 0 if share_device else int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != a.gpus and world > 1:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
@@ -206,7 +210,10 @@ def main():
                 sk.bind(("127.0.0.1", 0))
                 os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if share_device:      # RCCL wants one GPU per rank; two ranks on one device rendezvous over gloo (CPU tensors)
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     torch.cuda.set_device(local_rank)
@@ -281,7 +288,7 @@ def main():
     den.profile_enable(a.steps)
     tm_all = telemetry.Sampler(local_rank).start()
     t_region0 = time.perf_counter()
-    dt, pixels = pkg.farm.timed_region(step, a.steps, 0, lambda: torch.cuda.synchronize(dev), dist=dist, device=dev)
+    dt, pixels = pkg.farm.timed_region(step, a.steps, 0, lambda: torch.cuda.synchronize(dev), dist=dist, device=None if share_device else dev)
     t_region1 = time.perf_counter()
 
     # per-kernel durations of the timed steps (HIP events on the launch stream)
@@ -369,7 +376,7 @@ def main():
                                    + ("; G-buffer handed over as planes written in place by the producer (svgf_denoise_planar)" if a.planar_inputs else "")
                                    + "; one independent sequence per GPU", "name": a.config,
                        "width": W, "height": H, "atrous_levels": 1 if a.config == "config1" else NLEVEL,
-                       "parallelism": f"replicas{world}"},
+                       "parallelism": f"replicas{world}" + ("-sharing-one-device(test-only)" if share_device else "")},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "traffic_measured_live": False, "traffic_provenance": traffic_note,

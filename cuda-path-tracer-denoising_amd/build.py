@@ -12,8 +12,12 @@ LIB = os.path.join(_HERE, "libsvgf_hip.so")
 ORACLE_DIR = os.path.join(ROOT, "oracle")
 ORACLE_LIB = os.path.join(ORACLE_DIR, "libsvgf_oracle.so")
 
-HIP_SOURCES = ["svgf_api.hip", "svgf_kernels.hip", "svgf_atrous_strip.hip", "svgf_atrous_lane.hip", "svgf_atrous_fused.hip", "svgf_atrous_lattice.hip", "svgf_synth.hip", "svgf_scene.hip", "svgf_display.hip"]
+HIP_SOURCES = ["svgf_api.hip", "svgf_kernels.hip", "svgf_atrous_strip.hip", "svgf_atrous_lane.hip", "svgf_atrous_lane_reuse.hip", "svgf_atrous_fused.hip", "svgf_atrous_lattice.hip", "svgf_synth.hip", "svgf_scene.hip", "svgf_display.hip"]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-function"]
+# Per-file flags.  svgf_atrous_fused.hip: SimplifyCFG's common-code sinking merges the last store of the "bilinear history" branch
+# with the last store of the "fallback consistency data" branch of the temporal stage into ONE store through a phi of two
+# pointers, which keeps those request registers in scratch memory (every load followed by s_waitcnt vmcnt(0) + scratch_store).
+HIPCC_FILE_FLAGS = {"svgf_atrous_fused.hip": ["-mllvm", "-simplifycfg-sink-common=false"]}
 
 
 def _newer(target: str, deps: list[str]) -> bool:
@@ -53,7 +57,8 @@ def build_hip(force: bool = False) -> str:
     with tempfile.TemporaryDirectory(prefix="svgf_build_") as scratch:
         objs = [os.path.join(scratch, os.path.basename(x) + ".o") for x in srcs]
         with concurrent.futures.ThreadPoolExecutor(max_workers=min(len(srcs), os.cpu_count() or 1)) as pool:
-            list(pool.map(lambda so: _run([hipcc_path()] + cflags + extra + ["-c", so[0], "-o", so[1]]), zip(srcs, objs)))
+            list(pool.map(lambda so: _run([hipcc_path()] + cflags + HIPCC_FILE_FLAGS.get(os.path.basename(so[0]), []) + extra + ["-c", so[0], "-o", so[1]]),
+                          zip(srcs, objs)))
         _run([hipcc_path(), "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", tmp])
     os.replace(tmp, LIB)              # atomic: concurrent ranks never see a half-written library
     return LIB

@@ -16,8 +16,10 @@
 #include "svgf_kernels.h"
 
 #define SVGF_MAX_KERNELS_PER_FRAME (SVGF_MAX_LEVELS + 4)
-// a row of the fused temporal + first-level kernel against a row of the plain lane kernel (measured)
-static const double kFusedRowFactor = 1.5;
+// a row of the fused temporal + first-level kernel against a row of the plain lane kernel, as measured at 1920x1080 (DESIGN.md
+// 5.8, profiles/r04_exp_fused_*.log: 225 us against 42.7 for the plain level, i.e. the fused kernel LOSES to temporal pass + level,
+// 57 + 49 us): with this factor the automatic choice never fuses; kernel_variant 6 forces it
+static const double kFusedRowFactor = 5.3;
 
 struct svgf_ctx {
     int device, W, H;
@@ -26,6 +28,9 @@ struct svgf_ctx {
     float *vp[3];          // zero-margined (W+2) x (H+2) copies of cv[k].w: what the step-16/32 levels take their 3x3 variance pre-blur from
     unsigned vp_valid;     // bit k: vp[k] holds the variance of cv[k]
     int use_vplane;        // 0 only for A/B measurements (environment SVGF_NO_VARIANCE_PLANE at svgf_create)
+    float4 *tp[2];         // cross-level reuse of the geometric terms: four terms per pixel, written by level L for level L+1 (lane kernels
+                           // only, svgf_atrous_lane_reuse.hip); allocated when a frame first has two consecutive lane-kernel levels
+    int use_reuse;         // 1 only for A/B measurements (environment SVGF_REUSE at svgf_create): measured a loss, profiles/r04_ab_reuse_*.log
     int n_cu;              // compute units of the context's device (launch-geometry cost model of the kernel choice)
     signed char lane_cheaper[8];   // per log2(step): -1 not evaluated yet, 1 the lane kernel's estimate is the lower one
     signed char fuse_pays;         // -1 not evaluated yet, 1: the fused temporal + first-level kernel is the cheaper way through both
@@ -120,17 +125,33 @@ extern "C" int svgf_params_default(SvgfParams *p)
     return SVGF_OK;
 }
 
+// History planes are allocated with kPlanePad bytes in front of and behind the W*H elements: the fused temporal + first-level
+// kernel reads the 3x3 window around a reprojected position as three 3-element row pieces, and a piece that starts one element
+// left of an image row's first pixel (or ends one right of its last) must stay inside the allocation at the plane's two ends.
+static const size_t kPlanePad = 128;
+static hipError_t plane_alloc(void **out, size_t bytes)
+{
+    char *raw = nullptr;
+    hipError_t e = hipMalloc((void **)&raw, bytes + 2 * kPlanePad);
+    if (e != hipSuccess) { *out = nullptr; return e; }
+    e = hipMemset(raw, 0, bytes + 2 * kPlanePad);
+    *out = raw + kPlanePad;
+    return e;
+}
+static void plane_free(void *p) { if (p) (void)hipFree((char *)p - kPlanePad); }
+
 static void free_all(svgf_ctx *c)
 {
-    for (int k = 0; k < 3; k++) if (c->cv[k]) (void)hipFree(c->cv[k]);
+    for (int k = 0; k < 3; k++) plane_free(c->cv[k]);
     for (int k = 0; k < 3; k++) if (c->vp[k]) (void)hipFree(c->vp[k]);
+    for (int k = 0; k < 2; k++) if (c->tp[k]) (void)hipFree(c->tp[k]);
     for (int k = 0; k < 2; k++) {
-        if (c->nrm[k]) (void)hipFree(c->nrm[k]);
-        if (c->gid[k]) (void)hipFree(c->gid[k]);
-        if (c->mom[k]) (void)hipFree(c->mom[k]);
-        if (c->hlen[k]) (void)hipFree(c->hlen[k]);
+        plane_free(c->nrm[k]);
+        plane_free(c->gid[k]);
+        plane_free(c->mom[k]);
+        plane_free(c->hlen[k]);
     }
-    for (int k = 0; k < 2; k++) if (c->pos[k]) (void)hipFree(c->pos[k]);
+    for (int k = 0; k < 2; k++) plane_free(c->pos[k]);
     if (c->albedo) (void)hipFree(c->albedo);
     if (c->cv_capture) (void)hipFree(c->cv_capture);
     if (c->st_in) (void)hipFree(c->st_in);
@@ -186,19 +207,20 @@ extern "C" int svgf_create(int device, int width, int height, svgf_ctx **out)
     c->device = device; c->W = width; c->H = height; c->n = (size_t)width * height;
     for (int k = 0; k < 16; k++) c->view_prev[k] = (k % 5 == 0) ? 1.0f : 0.0f;
     c->use_vplane = getenv("SVGF_NO_VARIANCE_PLANE") ? 0 : 1;
+    c->use_reuse = getenv("SVGF_REUSE") ? 1 : 0;
     if (hipDeviceGetAttribute(&c->n_cu, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || c->n_cu < 8) c->n_cu = 256;
     memset(c->lane_cheaper, -1, sizeof(c->lane_cheaper));
     c->fuse_pays = -1;
     bool ok = true;
-    for (int k = 0; k < 3 && ok; k++) ok = hipMalloc((void **)&c->cv[k], c->n * sizeof(float4)) == hipSuccess;
+    for (int k = 0; k < 3 && ok; k++) ok = plane_alloc((void **)&c->cv[k], c->n * sizeof(float4)) == hipSuccess;
     // (+64 bytes: the step-16/32 lane kernel reads the variance plane in 16-byte pieces that may end 8 bytes behind the last margin)
     for (int k = 0; k < 3 && ok; k++) ok = hipMalloc((void **)&c->vp[k], (size_t)(width + 2) * (height + 2) * sizeof(float) + 64) == hipSuccess;
     for (int k = 0; k < 2 && ok; k++) {
-        ok = ok && hipMalloc((void **)&c->nrm[k], c->n * 3 * sizeof(float)) == hipSuccess;
-        ok = ok && hipMalloc((void **)&c->gid[k], c->n * sizeof(int)) == hipSuccess;
-        ok = ok && hipMalloc((void **)&c->mom[k], c->n * sizeof(float2)) == hipSuccess;
-        ok = ok && hipMalloc((void **)&c->hlen[k], c->n * sizeof(int)) == hipSuccess;
-        ok = ok && hipMalloc((void **)&c->pos[k], c->n * 3 * sizeof(float)) == hipSuccess;
+        ok = ok && plane_alloc((void **)&c->nrm[k], c->n * 3 * sizeof(float)) == hipSuccess;
+        ok = ok && plane_alloc((void **)&c->gid[k], c->n * sizeof(int)) == hipSuccess;
+        ok = ok && plane_alloc((void **)&c->mom[k], c->n * sizeof(float2)) == hipSuccess;
+        ok = ok && plane_alloc((void **)&c->hlen[k], c->n * sizeof(int)) == hipSuccess;
+        ok = ok && plane_alloc((void **)&c->pos[k], c->n * 3 * sizeof(float)) == hipSuccess;
     }
     if (!ok) {
         snprintf(g_create_err, sizeof(g_create_err), "svgf_create: hipMalloc failed for %dx%d", width, height);
@@ -482,6 +504,7 @@ static int denoise_frame(svgf_ctx *c, void *out_rgb_dev, const void *in_rgb_dev,
         LAUNCH(SVGF_KERNEL_COPYOUT, launch_copy_rgb(c->cv[c->hist], out, n, s));                 // (:382)
     } else {
         int src = c->hist;
+        int prev_terms = -1, prev_step = 0;      // tp[] index the previous level stored its geometric terms in, and that level's step
         for (int level = 1; level <= p->atrous_nlevel; level++) {
             const bool last = (level == p->atrous_nlevel);
             const bool keep = (level == p->history_level);      // this level's output becomes the colour history (:391)
@@ -503,6 +526,7 @@ static int denoise_frame(svgf_ctx *c, void *out_rgb_dev, const void *in_rgb_dev,
             // plane (see below); the lane kernel at those steps REQUIRES it (its loaders blur the variance from it)
             a.var = (c->use_vplane && a.step >= 16 && ((c->vp_valid >> src) & 1u)) ? c->vp[src] : nullptr;
             a.var_dst = nullptr;
+            a.tin = nullptr; a.tout = nullptr; a.t_m = 0; a.t_m_out = 0;
             bool strip = false, lattice = false;
             if (p->kernel_variant != 1) {
                 strip = atrous_strip_supported(a);
@@ -527,6 +551,26 @@ static int denoise_frame(svgf_ctx *c, void *out_rgb_dev, const void *in_rgb_dev,
                 if (dst >= 0 && !last && a.step >= 8) a.var_dst = c->vp[dst];
             }
             if (dst >= 0) { if (a.var_dst) c->vp_valid |= 1u << dst; else c->vp_valid &= ~(1u << dst); }
+            // Cross-level reuse of the geometric terms (svgf_atrous_lane_reuse.hip): a lane-kernel level reads the four terms the
+            // previous lane-kernel level stored for it (its step is twice that level's), and stores four for the next level if that
+            // one will run the lane kernel at twice this step.
+            int terms_out = -1;
+            if (which == K_LANE && c->use_reuse) {
+                if (prev_terms >= 0 && a.step == 2 * prev_step) { a.tin = c->tp[prev_terms]; a.t_m = (c->W + a.step - 1) / a.step; }
+                if (!last && 2 * a.step <= 32) {
+                    AtrousArgs nx = a;
+                    nx.step = 2 * a.step;
+                    nx.var = (c->use_vplane && nx.step >= 16 && a.var_dst) ? a.var_dst : nullptr;
+                    const bool next_lane = atrous_strip_supported(nx) && atrous_lane_supported(nx) &&
+                                           (p->kernel_variant >= 4 || (p->kernel_variant == 0 && lane_pays(c, nx)));
+                    if (next_lane) {
+                        terms_out = (prev_terms == 0) ? 1 : 0;
+                        if (!c->tp[terms_out]) HIPC(c, hipMalloc((void **)&c->tp[terms_out], (size_t)(c->W + 64) * c->H * sizeof(float4)));
+                        a.tout = c->tp[terms_out]; a.t_m_out = (c->W + nx.step - 1) / nx.step;
+                    }
+                }
+            }
+            prev_terms = terms_out; prev_step = a.step;
             switch (which) {
             case K_FUSED:
                 // the accumulated plane itself is only written when something besides this level reads it: a later frame (the
@@ -573,8 +617,11 @@ extern "C" int svgf_planar_gbuffer(svgf_ctx *c, SvgfPlanarGBuffer *out)
     SvgfDeviceGuard dev_guard(c->device);
     if (!dev_guard.ok) { snprintf(c->err, sizeof(c->err), "hipSetDevice(%d) failed", c->device); return SVGF_ERR_HIP; }
     if (!c->albedo) {
+        // (first call only.  The clear runs on the legacy stream; the producer that fills the plane may run on a non-blocking
+        // stream that does not order itself behind it: the clear is complete before the pointer leaves this function.)
         HIPC(c, hipMalloc((void **)&c->albedo, c->n * 3 * sizeof(float)));
         HIPC(c, hipMemset(c->albedo, 0, c->n * 3 * sizeof(float)));
+        HIPC(c, hipStreamSynchronize(nullptr));
     }
     const int gnew = 1 - c->gcur;        // the planes the next frame's temporal / prepare pass treats as "current"
     out->normal = c->nrm[gnew]; out->position = c->pos[gnew]; out->geom_id = c->gid[gnew]; out->albedo = c->albedo;

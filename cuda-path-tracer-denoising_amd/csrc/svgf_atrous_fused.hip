@@ -18,7 +18,7 @@
 bool atrous_fused_supported(const AtrousArgs &a, const TemporalArgs &t)
 {
     if (a.step != 2) return false;                                   // the reference's first level (src/denoise.cu:98,386)
-    if ((long long)a.W * a.H * 16 >= (1LL << 32)) return false;
+    if ((long long)a.W * a.H * 52 >= (1LL << 32)) return false;      // 32-bit byte offsets, the AoS texel being the widest element
     if (t.pos_tol > 0.0f) return false;                              // f4 extension, k_temporal only
     return true;
 }

@@ -118,9 +118,23 @@ __device__ __forceinline__ float lane_from(float v)
 // the temporal pass be fused into this level (FUSED): the loader waves PRODUCE the rows they stage (svgf_temporal.h, the
 // arithmetic of k_temporal) instead of loading them, and the accumulated variance of rows y +- 1 exists nowhere but in the ring.
 struct LaneNoTemporal {};
-template <int LOG2S, bool HASVAR, int LOG2P = LOG2S, int LOG2Y = 0, bool FUSED = false>
+//
+// REUSE (round 4): the geometric part of a pair's exponent, g(p, q) = kn |n_p - n_q| + kx |x_p - x_q|, does not depend on the
+// level, and the pairs at lattice offsets (+2, 0), (-2, +2), (0, +2), (+2, +2) of step S ARE the pairs at offsets (+1, 0), (-1, +1),
+// (0, +1), (+1, +1) of step 2S: four of the twelve forward terms of every level after the first were evaluated by the level
+// before.  Bit 1 (OUT): a lane stores those four terms of its centre (minus the level's -log2 h constants) as one float4 in
+// a.tout[p]; bit 0 (IN): it reads them from a.tin[p] one iteration ahead and skips four of its twelve geometry evaluations
+// (24 packed + 8 plain VALU, 8 v_sqrt and 4 ds_read_b128 per pixel) for one 16-byte load and four additions.
+// MEASURED (profiles/r04_ab_reuse_*.log): parity-green and a LOSS — 265 -> 275 us per 1080p frame at best (coalesced plane),
+// 292 with the pixel-major plane, 956 -> 1154 us at 4K.  The compute waves of this kernel issue no vector-memory LOAD and one
+// 16-byte store per lane and row; one more store costs a level 2.5 us (the eight waves store in lock step: the output stage
+// grows from ~300 to ~600 of 5 300 ticks), one load 1-4 us (its first use waits, in order, for the previous row's stores),
+// against ~3 us the four evaluations are worth, and at 4K the two extra planes (266 MB per level) meet an HBM that is no longer
+// half idle.  Off by default (environment SVGF_REUSE=1 turns it on); kept because it is correct and small.
+template <int LOG2S, bool HASVAR, int LOG2P = LOG2S, int LOG2Y = 0, bool FUSED = false, int REUSE = 0>
 __global__ __launch_bounds__(NT) void k_atrous_lane(AtrousArgs a, LaneGeom gm, std::conditional_t<FUSED, TemporalArgs, LaneNoTemporal> ta)
 {
+    constexpr bool REUSE_IN = (REUSE & 1) != 0, REUSE_OUT = (REUSE & 2) != 0;
     constexpr int S = 1 << LOG2S;
     constexpr int P = 1 << LOG2P;                // x-phases held by one workgroup
     constexpr int YP = 1 << LOG2Y;               // y-phases held by one workgroup
@@ -143,6 +157,8 @@ __global__ __launch_bounds__(NT) void k_atrous_lane(AtrousArgs a, LaneGeom gm, s
     constexpr int BLUR_BUF = (YP > 1) ? 0 : (CHUNKED ? P * M : 2 * BLUR_ROW);      // [y-1 | y+1], or the blurred variance [phase][column]; none with both y-phases in the ring
     constexpr int TXL = LOUT * WPP;              // lattice columns a workgroup outputs per phase
     static_assert(CHUNKED || RW == TXW + 4 * S, "layout");
+    // chunked x-phases: each loader thread of a group blurs ONE unit of four staged columns per row (vblur_load / vblur_store)
+    static_assert(!CHUNKED || RW / 4 <= kLoaderGroup, "the loader-side variance blur covers a row with one unit per loader thread");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float *blur = reinterpret_cast<float *>(smem + RING_BYTES);           // [iteration parity][y-1 | y+1][phase][BM]
@@ -423,278 +439,288 @@ __global__ __launch_bounds__(NT) void k_atrous_lane(AtrousArgs a, LaneGeom gm, s
     // colour + variance into the ring record (nowhere else: level 1's output is the next colour history, :391) and, for
     // the pixels the workgroup OWNS (its output rows and columns; halo pixels are recomputed by the neighbours), the
     // moments, the history length and the split G-buffer planes.  A pixel passes three stages, each one memory round trip:
-    //   A  primary loads: 1-spp colour, normal / position / geomId (AoS texel or the producer's planes), history length;
+    //   A  primary loads: normal / position / geomId (AoS texel or the producer's planes), history length;
     //   B  reprojection; loads of previous-frame geomId + normal of the four bilinear taps (isReprjValid :172-182);
-    //   C  consistency test; history loads of the valid taps, bilinear (:234-259) or — blocking, rare in steady state —
-    //      the 3x3 fallback (:262-286); blend (:288-315); ring record + planes.
-    // In the loop a loader thread owns one staged column and both y-phases of it and runs C(row b+3), B(row b+4), A(row b+5)
-    // during iteration b, so that every stage's loads have a whole iteration to land.
+    //   C  consistency test; then, in ONE batch for both pixels of a thread, the 1-spp colour and the history of the bilinear
+    //      quad (:234-259) or the consistency data of the 3x3 fallback's other five taps (:262-286, whose history follows row
+    //      by row, blocking); blend (:288-315); ring record + planes.
+    // What a pixel carries from stage to stage is kept small on purpose — the loader waves have the 168 registers three waves
+    // per SIMD leave: the colour is fetched in stage C rather than in A (3 registers), ring record and pixel index are re-derived.
     // ====================================================================================================================
-    struct TPx {
-        float cr, cg, cb, nx, ny, nz, px, py, pz;      // A
-        int gid, N;
-        float fx, fy, fracx, fracy;                     // B
-        int gq[4];
-        float nq[4][3];
-        int lds_off;       // ring record (byte offset)
-        unsigned p;        // pixel index (clamped into the image for out-of-image pixels)
-        int flags;         // 1: pixel inside the image, 2: owned (planes are written), 4: history lookup (N > 0 && geomId != -1), 8 << k: tap k consistent
+    struct TA_ { float nx, ny, nz, px, py, pz; int gid, N; };                         // stage A: primary data
+    struct TB_ { int g4[4]; float nq[12]; };                                            // stage B: geomId + normal of the bilinear quad (0,0) (1,0) (0,1) (1,1)
+    // stage C request: d[6k .. 6k+5] = {colour, moments, length} of quad tap k (mode 1), or d[3j .. 3j+2] = normal and d[15 + j] =
+    // geomId of the fallback's extra tap j (mode 2); rgb = the pixel's 1-spp colour
+    struct TC_ { float d[24]; float cr, cg, cb; SvgfReproj rp; int mode, m9; };
+    // Element index (+ 2) of the 3x3 window's row yy (-1, 0, 1), first column (fx - 1).  Rows are clamped into the image, the
+    // first column into [-2, W - 1]: a window with any tap on screen has fx in [-1, W] and is read where it lies — its off-screen
+    // taps fall at most two elements outside a row, i.e. inside the planes' padding at the two ends of a plane (svgf_api.hip:
+    // kPlanePad) — and every tap's validity comes from svgf_tap_index() on the float coordinates, never from the address.
+    // The + 2 makes it a non-negative offset from (plane - 2 elements): with an unsigned 32-bit offset the loads take the
+    // scalar-base + vector-offset form (one address register instead of a 64-bit pair per load).
+    [[maybe_unused]] auto t_window_row = [&](float fx, float fy, int yy) -> unsigned {
+        const float fxc = fminf(fmaxf(fx, -1.0f), (float)W);              // NaN -> -1
+        const float fyc = fminf(fmaxf(fy + (float)yy, 0.0f), (float)(H - 1));
+        return (unsigned)((int)fyc * W + ((int)fxc + 1));
     };
-    struct THist { float ch[4][3], mh[4][2]; int hl[4]; int mode; };     // mode 0: no history, 1: bilinear, 2: 3x3 fallback
-    [[maybe_unused]] auto t_stage_a = [&](TPx &t, int lds_off, unsigned p, int flags) {
-        if constexpr (FUSED) {
-            t.lds_off = lds_off; t.p = p; t.flags = flags;
-            const float *c = ta.in_rgb + 3 * (size_t)p;
-            t.cr = c[0]; t.cg = c[1]; t.cb = c[2];
-            if (ta.gbuf) {
-                const float *g = ta.gbuf + 13 * (size_t)p;
-                t.nx = g[0]; t.ny = g[1]; t.nz = g[2]; t.px = g[3]; t.py = g[4]; t.pz = g[5];
-                t.gid = __float_as_int(g[12]);
-            } else {
-                const float *n = ta.nrm_cur + 3 * (size_t)p, *q = ta.pos_cur + 3 * (size_t)p;
-                t.nx = n[0]; t.ny = n[1]; t.nz = n[2]; t.px = q[0]; t.py = q[1]; t.pz = q[2];
-                t.gid = ta.gid_cur[p];
-            }
-            t.N = ta.hlen[p];
-        }
+    [[maybe_unused]] auto t_at = [](const void *plane, unsigned elem_plus_2, unsigned elem_bytes) -> const char * {
+        return reinterpret_cast<const char *>(plane) - 2 * (long)elem_bytes + elem_plus_2 * elem_bytes;
     };
-    [[maybe_unused]] auto t_stage_b = [&](TPx &t) {
-        if constexpr (FUSED) {
-            const bool hist = (t.flags & 1) && t.N > 0 && t.gid != -1;
-            t.fx = 0.0f; t.fy = 0.0f; t.fracx = 0.0f; t.fracy = 0.0f;
-#pragma unroll
-            for (int k = 0; k < 4; k++) { t.gq[k] = -1; t.nq[k][0] = 0.0f; t.nq[k][1] = 0.0f; t.nq[k][2] = 0.0f; }
-            if (hist) {
-                t.flags |= 4;
-                const SvgfReproj rp = svgf_reproject(ta, t.px, t.py, t.pz);
-                t.fx = rp.fx; t.fy = rp.fy; t.fracx = rp.fracx; t.fracy = rp.fracy;
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    const int q = svgf_tap_index(ta, rp.fx + (float)(k & 1), rp.fy + (float)(k >> 1));
-                    if (q >= 0) {
-                        t.gq[k] = ta.gid_prev[q];
-                        const float *n = ta.nrm_prev + 3 * (size_t)q;
-                        t.nq[k][0] = n[0]; t.nq[k][1] = n[1]; t.nq[k][2] = n[2];
-                    }
-                }
-            }
-        }
-    };
-    [[maybe_unused]] auto t_stage_c1 = [&](TPx &t, THist &h) {
-        if constexpr (FUSED) {
-            h.mode = 0;
-            if (t.flags & 4) {
-                bool all = (t.fx >= 0.0f && t.fy >= 0.0f && t.fx < (float)W && t.fy < (float)H);
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    // (a tap outside the screen kept gq = -1, which fails the consistency test like the bounds test would)
-                    const bool ok = svgf_tap_consistent(t.gq[k], t.nq[k][0], t.nq[k][1], t.nq[k][2], t.gid, t.nx, t.ny, t.nz);
-                    if (ok) t.flags |= 8 << k;
-                    all = all && ok;
-                }
-                h.mode = all ? 1 : 2;
-                if (all) {
-#pragma unroll
-                    for (int k = 0; k < 4; k++) {
-                        const int q = svgf_tap_index(ta, t.fx + (float)(k & 1), t.fy + (float)(k >> 1));
-                        const float *c = reinterpret_cast<const float *>(ta.cv_hist + q);
-                        h.ch[k][0] = c[0]; h.ch[k][1] = c[1]; h.ch[k][2] = c[2];
-                        const float2 m = ta.mom_hist[q];
-                        h.mh[k][0] = m.x; h.mh[k][1] = m.y;
-                        h.hl[k] = ta.hlen[q];
-                    }
-                }
-            }
-        }
-    };
-    [[maybe_unused]] auto t_stage_c2 = [&](TPx &t, const THist &h) {
-        if constexpr (FUSED) {
-            const float lum = svgf_lum_strict(t.cr, t.cg, t.cb);
-            SvgfHistSum hs = { 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f };
-            bool valid = false;
-            if (h.mode == 1) {                                        // bilinear (:234-259)
-                float w[4];
-                svgf_bilinear_weights(t.fracx, t.fracy, w);
-                float sumw = 0.0f;
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    svgf_hist_add_weighted(hs, w[k], h.ch[k][0], h.ch[k][1], h.ch[k][2], h.mh[k][0], h.mh[k][1], h.hl[k]);
-                    sumw += w[k];
-                }
-                if ((double)sumw >= 0.01) svgf_hist_div(hs, sumw);
-                valid = true;
-            } else if (h.mode == 2) {                                 // 3x3 box around floor (:262-286)
-                // Two batched round trips instead of eighteen dependent ones: consistency data of the five taps outside the
-                // bilinear quad (the quad's own four were tested in stage C1), then the history of every tap that passed;
-                // the sum runs in the reference's raster order.  Pixels whose whole 3x3 window lies outside the screen (at
-                // 16:9 the reference's mapping sends 44 % of the pixels there) issue nothing.
-                int q9[9];
-#pragma unroll
-                for (int k = 0; k < 9; k++) {
-                    const int xx = k % 3 - 1, yy = k / 3 - 1;
-                    q9[k] = svgf_tap_index(ta, t.fx + (float)xx, t.fy + (float)yy);
-                    if (xx >= 0 && yy >= 0 && !((t.flags >> (3 + xx + 2 * yy)) & 1)) q9[k] = -1;
-                }
-                {
-                    constexpr int extra[5] = { 0, 1, 2, 3, 6 };
-                    int g5[5];
-                    float n5[5][3];
-#pragma unroll
-                    for (int j = 0; j < 5; j++) {
-                        const int q = q9[extra[j]];
-                        g5[j] = -1; n5[j][0] = 0.0f; n5[j][1] = 0.0f; n5[j][2] = 0.0f;
-                        if (q >= 0) {
-                            g5[j] = ta.gid_prev[q];
-                            const float *n = ta.nrm_prev + 3 * (size_t)q;
-                            n5[j][0] = n[0]; n5[j][1] = n[1]; n5[j][2] = n[2];
-                        }
-                    }
-#pragma unroll
-                    for (int j = 0; j < 5; j++)
-                        if (q9[extra[j]] >= 0 && !svgf_tap_consistent(g5[j], n5[j][0], n5[j][1], n5[j][2], t.gid, t.nx, t.ny, t.nz)) q9[extra[j]] = -1;
-                }
-                float c9[9][3], m9[9][2];
-                int l9[9];
-#pragma unroll
-                for (int k = 0; k < 9; k++) {
-                    c9[k][0] = 0.0f; c9[k][1] = 0.0f; c9[k][2] = 0.0f; m9[k][0] = 0.0f; m9[k][1] = 0.0f; l9[k] = 0;
-                    if (q9[k] >= 0) {
-                        const float *c = reinterpret_cast<const float *>(ta.cv_hist + q9[k]);
-                        c9[k][0] = c[0]; c9[k][1] = c[1]; c9[k][2] = c[2];
-                        const float2 m = ta.mom_hist[q9[k]];
-                        m9[k][0] = m.x; m9[k][1] = m.y;
-                        l9[k] = ta.hlen[q9[k]];
-                    }
-                }
-                float cnt = 0.0f;
-#pragma unroll
-                for (int k = 0; k < 9; k++)
-                    if (q9[k] >= 0) { svgf_hist_add(hs, c9[k][0], c9[k][1], c9[k][2], m9[k][0], m9[k][1], l9[k]); cnt += 1.0f; }
-                if (cnt > 0.0f) { svgf_hist_div(hs, cnt); valid = true; }
-            }
-            const SvgfTemporalOut o = svgf_temporal_blend(ta, t.cr, t.cg, t.cb, lum, t.N, valid, hs);
-            // ring record, as rows_store() writes it
-            const bool ok = (t.flags & 1) != 0;
-            const float inf = __builtin_huge_valf();
-            const float mag = fabsf(t.nx) + fabsf(t.ny) + fabsf(t.nz) + fabsf(t.px) + fabsf(t.py) + fabsf(t.pz);
-            if (!(mag < inf)) *nan_seen = 1;
-            char *d = smem + t.lds_off;
-            *reinterpret_cast<float4 *>(d) = make_float4(t.nx, t.px, t.ny, t.py);
-            *reinterpret_cast<float4 *>(d + 16) = make_float4(t.nz, t.pz, ok ? lum_f64(o.cv.x, o.cv.y, o.cv.z) : inf, 0.0f);
-            *reinterpret_cast<float4 *>(d + 32) = ok ? o.cv : make_float4(0.f, 0.f, 0.f, 0.f);
-            if (t.flags & 2) {                                        // owned: the planes the rest of the frame (and the next) reads
-                ta.hlen_upd[t.p] = o.hlen;
-                ta.mom_acc[t.p] = o.mom;
-                if (ta.cv_acc) ta.cv_acc[t.p] = o.cv;                 // only when a test captures the accumulated plane
-                if (ta.gbuf) {
-                    float *n = ta.nrm_cur + 3 * (size_t)t.p, *q = ta.pos_cur + 3 * (size_t)t.p;
-                    n[0] = t.nx; n[1] = t.ny; n[2] = t.nz; q[0] = t.px; q[1] = t.py; q[2] = t.pz;
-                    ta.gid_cur[t.p] = t.gid;
-                }
-            }
-        }
-    };
-    // staged pixel (lattice row br, y-phase yp, staged column xi) -> ring record, pixel index, flags
-    [[maybe_unused]] auto t_describe = [&](int br, int yp, int xi, int slot, bool active, int &lds_off, unsigned &p, int &flags) {
+    // pixel (lattice row br, y-phase yp, staged column xi) -> ring record, pixel index, flags (1: inside the image, 2: owned)
+    [[maybe_unused]] auto t_describe = [&](int br, int yp, int xi, bool active, int &lds_off, unsigned &p, int &flags) {
         const int y = phase + yp + (br << LOG2S);
         const int xs = xs_of(xi);
         const bool ok = active && (br >= 0) && (y < H) && (xs >= 0) && (xs < W);
         const bool owned = ok && (br >= b0) && (br < b1) && (xi >= 2 * S) && (xi < 2 * S + TXW);
-        lds_off = (slot * YP + yp) * ROWB + rec_of(xi);
+        lds_off = active ? (slot_mod(br) * YP + yp) * ROWB + rec_of(xi) : -1;      // an idle slot must not store anything
         p = (unsigned)min(max(y, 0), H - 1) * (unsigned)W + (unsigned)min(max(xs, 0), W - 1);
         flags = (ok ? 1 : 0) | (owned ? 2 : 0);
     };
+    [[maybe_unused]] auto t_stage_a = [&](TA_ &t, unsigned p) {
+        if constexpr (FUSED) {
+            // (unsigned 32-bit byte offsets: scalar base + vector offset addressing; W * H * 52 < 2^32 is checked by the launcher)
+            if (ta.gbuf) {
+                const float *g = reinterpret_cast<const float *>(reinterpret_cast<const char *>(ta.gbuf) + p * 52u);
+                t.nx = g[0]; t.ny = g[1]; t.nz = g[2]; t.px = g[3]; t.py = g[4]; t.pz = g[5];
+                t.gid = __float_as_int(g[12]);
+            } else {
+                const float *n = reinterpret_cast<const float *>(reinterpret_cast<const char *>(ta.nrm_cur) + p * 12u);
+                const float *q = reinterpret_cast<const float *>(reinterpret_cast<const char *>(ta.pos_cur) + p * 12u);
+                t.nx = n[0]; t.ny = n[1]; t.nz = n[2]; t.px = q[0]; t.py = q[1]; t.pz = q[2];
+                t.gid = *reinterpret_cast<const int *>(reinterpret_cast<const char *>(ta.gid_cur) + p * 4u);
+            }
+            t.N = *reinterpret_cast<const int *>(reinterpret_cast<const char *>(ta.hlen) + p * 4u);
+        }
+    };
+    // history lookup wanted (:197): the pixel is inside the image, has a history and hit something
+    [[maybe_unused]] auto t_wants_history = [&](const TA_ &a_, int flags) { return (flags & 1) && a_.N > 0 && a_.gid != -1; };
+    [[maybe_unused]] auto t_stage_b = [&](const TA_ &a_, int flags, TB_ &b_, SvgfReproj &rp_out) {
+        if constexpr (FUSED) {
+            if (t_wants_history(a_, flags)) {
+                const SvgfReproj rp = svgf_reproject(ta, a_.px, a_.py, a_.pz);
+                rp_out = rp;
+#pragma unroll
+                for (int yy = 0; yy <= 1; yy++) {                         // the bilinear quad: taps (0, yy), (1, yy), one row piece each
+                    const unsigned e = t_window_row(rp.fx, rp.fy, yy) + 1u;
+                    const int *gp = reinterpret_cast<const int *>(t_at(ta.gid_prev, e, 4u));
+                    const float *np = reinterpret_cast<const float *>(t_at(ta.nrm_prev, e, 12u));
+                    b_.g4[2 * yy] = gp[0]; b_.g4[2 * yy + 1] = gp[1];
+#pragma unroll
+                    for (int j = 0; j < 6; j++) b_.nq[6 * yy + j] = np[j];
+                }
+            }
+        }
+    };
+    [[maybe_unused]] auto t_stage_c1 = [&](const TA_ &a_, const TB_ &b_, const SvgfReproj &rp_in, int flags, unsigned p, TC_ &c_) {
+        if constexpr (FUSED) {
+            const float *c = reinterpret_cast<const float *>(reinterpret_cast<const char *>(ta.in_rgb) + p * 12u);
+            c_.cr = c[0]; c_.cg = c[1]; c_.cb = c[2];
+            c_.mode = 0; c_.m9 = 0;
+            c_.rp.fx = 0.0f; c_.rp.fy = 0.0f; c_.rp.fracx = 0.0f; c_.rp.fracy = 0.0f;
+            if (t_wants_history(a_, flags)) {
+                const SvgfReproj rp = rp_in;
+                c_.rp = rp;
+                int m9 = 0;                                               // taps on screen (:173-176), bit (yy + 1) * 3 + xx + 1
+#pragma unroll
+                for (int k = 0; k < 9; k++)
+                    m9 |= (svgf_tap_index(ta, rp.fx + (float)(k % 3 - 1), rp.fy + (float)(k / 3 - 1)) >= 0) ? (1 << k) : 0;
+                // the bilinear quad: window taps 4, 5, 7, 8; its geomIds and normals are here: consistency test (:177-180)
+                constexpr int quad[4] = { 4, 5, 7, 8 };
+                bool all = (rp.fx >= 0.0f && rp.fy >= 0.0f && rp.fx < (float)W && rp.fy < (float)H);
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const bool ok = ((m9 >> quad[k]) & 1) & svgf_tap_consistent(b_.g4[k], b_.nq[3 * k], b_.nq[3 * k + 1], b_.nq[3 * k + 2], a_.gid, a_.nx, a_.ny, a_.nz);
+                    if (!ok) m9 &= ~(1 << quad[k]);
+                    all = all && ok;
+                }
+                c_.m9 = m9;
+                c_.mode = all ? 1 : 2;
+                if (all) {                                                // bilinear: the quad's history, two row pieces
+#pragma unroll
+                    for (int yy = 0; yy <= 1; yy++) {
+                        const unsigned e = t_window_row(rp.fx, rp.fy, yy) + 1u;
+                        const float *ch = reinterpret_cast<const float *>(t_at(ta.cv_hist, e, 16u));
+                        const float *m = reinterpret_cast<const float *>(t_at(ta.mom_hist, e, 8u));
+                        const int *l = reinterpret_cast<const int *>(t_at(ta.hlen, e, 4u));
+#pragma unroll
+                        for (int xx = 0; xx <= 1; xx++) {
+                            const int k = 2 * yy + xx;
+                            c_.d[6 * k] = ch[4 * xx]; c_.d[6 * k + 1] = ch[4 * xx + 1]; c_.d[6 * k + 2] = ch[4 * xx + 2];
+                            c_.d[6 * k + 3] = m[2 * xx]; c_.d[6 * k + 4] = m[2 * xx + 1];
+                            c_.d[6 * k + 5] = __int_as_float(l[xx]);
+                        }
+                    }
+                } else if (m9 & 0x4f) {                                   // fallback: geomId + normal of the on-screen taps 0, 1, 2, 3, 6
+                    {
+                        const unsigned e = t_window_row(rp.fx, rp.fy, -1);
+                        const float *np = reinterpret_cast<const float *>(t_at(ta.nrm_prev, e, 12u));
+                        const int *gp = reinterpret_cast<const int *>(t_at(ta.gid_prev, e, 4u));
+#pragma unroll
+                        for (int k = 0; k < 9; k++) c_.d[k] = np[k];
+#pragma unroll
+                        for (int k = 0; k < 3; k++) c_.d[15 + k] = __int_as_float(gp[k]);
+                    }
+#pragma unroll
+                    for (int yy = 0; yy <= 1; yy++) {
+                        const unsigned e = t_window_row(rp.fx, rp.fy, yy);
+                        const float *np = reinterpret_cast<const float *>(t_at(ta.nrm_prev, e, 12u));
+                        c_.d[9 + 3 * yy] = np[0]; c_.d[10 + 3 * yy] = np[1]; c_.d[11 + 3 * yy] = np[2];
+                        c_.d[18 + yy] = __int_as_float(*reinterpret_cast<const int *>(t_at(ta.gid_prev, e, 4u)));
+                    }
+                }
+            }
+        }
+    };
+    [[maybe_unused]] auto t_stage_c2 = [&](const TA_ &a_, const TC_ &c_, int flags, unsigned p, int lds_off) {
+        if constexpr (FUSED) {
+            const float lum = svgf_lum_strict(c_.cr, c_.cg, c_.cb);
+            SvgfHistSum hs = { 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f };
+            bool valid = false;
+            if (c_.mode == 1) {                                       // bilinear (:234-259)
+                float w[4];
+                svgf_bilinear_weights(c_.rp.fracx, c_.rp.fracy, w);
+                float sumw = 0.0f;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    svgf_hist_add_weighted(hs, w[k], c_.d[6 * k], c_.d[6 * k + 1], c_.d[6 * k + 2], c_.d[6 * k + 3], c_.d[6 * k + 4], __float_as_int(c_.d[6 * k + 5]));
+                    sumw += w[k];
+                }
+                if ((double)sumw >= 0.01) svgf_hist_div(hs, sumw);
+                valid = true;
+            } else if (c_.mode == 2) {                                // 3x3 box around floor (:262-286)
+                int m9 = c_.m9;
+                constexpr int extra[5] = { 0, 1, 2, 3, 6 };
+                if (m9 & 0x4f) {                                      // (the condition stage C1 requested their data under)
+#pragma unroll
+                    for (int j = 0; j < 5; j++)
+                        if (!svgf_tap_consistent(__float_as_int(c_.d[15 + j]), c_.d[3 * j], c_.d[3 * j + 1], c_.d[3 * j + 2], a_.gid, a_.nx, a_.ny, a_.nz)) m9 &= ~(1 << extra[j]);
+                }
+                if (m9) {                                             // a consistent tap exists: the window's history, one row piece at a time
+                    float cnt = 0.0f;
+#pragma unroll 1
+                    for (int yy = -1; yy <= 1; yy++) {
+                        const int mrow = (m9 >> ((yy + 1) * 3)) & 7;
+                        if (mrow) {
+                            const unsigned e = t_window_row(c_.rp.fx, c_.rp.fy, yy);
+                            const float *ch = reinterpret_cast<const float *>(t_at(ta.cv_hist, e, 16u));
+                            const float *m = reinterpret_cast<const float *>(t_at(ta.mom_hist, e, 8u));
+                            const int *l = reinterpret_cast<const int *>(t_at(ta.hlen, e, 4u));
+                            float c3[3][3], mo3[3][2];
+                            int l3[3];
+#pragma unroll
+                            for (int xx = 0; xx < 3; xx++) {
+                                c3[xx][0] = ch[4 * xx]; c3[xx][1] = ch[4 * xx + 1]; c3[xx][2] = ch[4 * xx + 2];
+                                mo3[xx][0] = m[2 * xx]; mo3[xx][1] = m[2 * xx + 1];
+                                l3[xx] = l[xx];
+                            }
+#pragma unroll
+                            for (int xx = 0; xx < 3; xx++)            // raster order, as the reference sums
+                                if ((mrow >> xx) & 1) { svgf_hist_add(hs, c3[xx][0], c3[xx][1], c3[xx][2], mo3[xx][0], mo3[xx][1], l3[xx]); cnt += 1.0f; }
+                        }
+                    }
+                    svgf_hist_div(hs, cnt);
+                    valid = true;
+                }
+            }
+            const SvgfTemporalOut o = svgf_temporal_blend(ta, c_.cr, c_.cg, c_.cb, lum, a_.N, valid, hs);
+            // ring record, as rows_store() writes it
+            const bool ok = (flags & 1) != 0;
+            const float inf = __builtin_huge_valf();
+            const float mag = fabsf(a_.nx) + fabsf(a_.ny) + fabsf(a_.nz) + fabsf(a_.px) + fabsf(a_.py) + fabsf(a_.pz);
+            if (!(mag < inf)) *nan_seen = 1;
+            char *d = smem + lds_off;
+            *reinterpret_cast<float4 *>(d) = make_float4(a_.nx, a_.px, a_.ny, a_.py);
+            *reinterpret_cast<float4 *>(d + 16) = make_float4(a_.nz, a_.pz, ok ? lum_f64(o.cv.x, o.cv.y, o.cv.z) : inf, 0.0f);
+            *reinterpret_cast<float4 *>(d + 32) = ok ? o.cv : make_float4(0.f, 0.f, 0.f, 0.f);
+            if (flags & 2) {                                          // owned: the planes the rest of the frame (and the next) reads
+                *reinterpret_cast<int *>(reinterpret_cast<char *>(ta.hlen_upd) + p * 4u) = o.hlen;
+                *reinterpret_cast<float2 *>(reinterpret_cast<char *>(ta.mom_acc) + p * 8u) = o.mom;
+                if (ta.cv_acc) *reinterpret_cast<float4 *>(reinterpret_cast<char *>(ta.cv_acc) + p * 16u) = o.cv;   // only when something besides this level reads the accumulated plane
+                if (ta.gbuf) {
+                    float *n = reinterpret_cast<float *>(reinterpret_cast<char *>(ta.nrm_cur) + p * 12u);
+                    float *q = reinterpret_cast<float *>(reinterpret_cast<char *>(ta.pos_cur) + p * 12u);
+                    n[0] = a_.nx; n[1] = a_.ny; n[2] = a_.nz; q[0] = a_.px; q[1] = a_.py; q[2] = a_.pz;
+                    *reinterpret_cast<int *>(reinterpret_cast<char *>(ta.gid_cur) + p * 4u) = a_.gid;
+                }
+            }
+        }
+    };
 
     if constexpr (FUSED) {
-        // ---------------- prologue: all 768 threads accumulate the ten ring rows b0-2 .. b0+2 (both y-phases), four pixels each,
-        // stage by stage; the loader threads also start row b0+3 (stages A, B) and row b0+4 (stage A) for the loop ----------------
-        constexpr int NP = (5 * YP * RW + NT - 1) / NT;
-        static_assert(NP == 4, "prologue: two halves of two pixels");
+        // One software pipeline for the prologue and the loop, ONE pixel per thread and sub-step.  Pixel q of a thread:
+        //   q = 0 .. 3     the ten prologue rows b0-2 .. b0+2 (both y-phases), dealt over all 768 threads, four pixels each;
+        //   q >= 4         lattice row b0+3 + (q-4)/2, y-phase (q-4) & 1, at the staged column a LOADER thread owns.
+        // Sub-step u runs stage C2 of pixel u-4, C1 of pixel u-3, B of pixel u-2 and A of pixel u: every stage's loads have at
+        // least one sub-step to land and no stage waits for a load it has just issued (the 3x3 fallback's history excepted).
+        // After sub-step 7 the prologue rows are in the ring (first barrier; the compute threads leave for their warm-up rows);
+        // sub-steps 8+2i, 9+2i are iteration i of the loop: they commit the two y-phases of lattice row bo+3 while the compute
+        // waves work on output row bo = b0+i.  One pixel per stage keeps the carried state at ~80 registers (two pixels per
+        // stage did not fit the 168 that three waves per SIMD leave: every variant spilled, and a spill reload inside the loop
+        // waits for every load in flight).
         const int lt = tid - NC;                        // loader thread index (loader threads only)
         const int lxi = min(max(lt, 0), RW - 1);        // the staged column a loader thread owns in the loop
         const bool lactive = is_loader && lt < RW;
-        TPx nx3[YP], nx4[YP];                           // rows b0+3, b0+4 of the loader's column
-        if (is_loader) {
-#pragma unroll
-            for (int yp = 0; yp < YP; yp++) {
-                int lo, fl; unsigned p;
-                t_describe(b0 + 3, yp, lxi, slot_mod(b0 + 3), lactive && (b0 + 3 <= b1 + 1), lo, p, fl);
-                t_stage_a(nx3[yp], lo, p, fl);
-            }
-        }
-        // two pixels at a time through all three stages (four at once do not fit the 168 registers three waves per SIMD leave)
-#pragma unroll 1
-        for (int h2 = 0; h2 < NP; h2 += 2) {
-            TPx tp[2];
-#pragma unroll
-            for (int m = 0; m < 2; m++) {
-                const int idx = tid + (h2 + m) * NT;
-                const bool active = idx < 5 * YP * RW;
+        auto describe_px = [&](int q, int &lo, unsigned &p, int &fl) {
+            int br, yp, xi;
+            bool active;
+            if (q < 4) {
+                const int idx = tid + q * NT;
+                active = idx < 5 * YP * RW;
                 const int idc = min(idx, 5 * YP * RW - 1);
-                const int rr = idc / RW, xi = idc - rr * RW;
-                const int br = b0 - 2 + rr / YP, yp = rr % YP;
-                int lo, fl; unsigned p;
-                t_describe(br, yp, xi, slot_mod(br), active, lo, p, fl);
-                // an inactive slot repeats the last pixel: it must not write anything
-                t_stage_a(tp[m], active ? lo : -1, p, fl);
+                const int rr = idc / RW;
+                xi = idc - rr * RW;
+                br = b0 - 2 + rr / YP; yp = rr % YP;
+            } else {
+                br = b0 + 3 + ((q - 4) >> 1); yp = (q - 4) & 1; xi = lxi;
+                active = lactive && br <= b1 + 1;
             }
-            t_stage_b(tp[0]);
-            t_stage_b(tp[1]);
-            THist th[2];
-            t_stage_c1(tp[0], th[0]);
-            t_stage_c1(tp[1], th[1]);
-            if (tp[0].lds_off >= 0) t_stage_c2(tp[0], th[0]);
-            if (tp[1].lds_off >= 0) t_stage_c2(tp[1], th[1]);
-        }
-        if (is_loader) {
-#pragma unroll
-            for (int yp = 0; yp < YP; yp++) {
-                t_stage_b(nx3[yp]);
+            t_describe(br, yp, xi, active, lo, p, fl);
+        };
+        TA_ a0, a1;                                     // stage A of pixels u-1, u-2
+        TA_ ab; TB_ bb; SvgfReproj rb;                  // the pixel between stages B and C1
+        TA_ ac; TC_ cc;                                 // the pixel between stages C1 and C2
+        rb.fx = rb.fy = rb.fracx = rb.fracy = 0.0f;
+        if (is_loader) __builtin_amdgcn_s_setprio(SVGF_LANE_LOADER_PRIO);
+        const int n_sub = 8 + 2 * (b1 - b0);
+#pragma unroll 1
+        for (int u = 0; u < n_sub; u++) {
+            if (u >= 8 && !(u & 1)) stamp(0);
+            if (u >= 4) {                               // C2: blend, ring record + planes
                 int lo, fl; unsigned p;
-                t_describe(b0 + 4, yp, lxi, slot_mod(b0 + 4), lactive && (b0 + 4 <= b1 + 1), lo, p, fl);
-                t_stage_a(nx4[yp], lo, p, fl);
+                describe_px(u - 4, lo, p, fl);
+                if (lo >= 0) t_stage_c2(ac, cc, fl, p, lo);
             }
-        }
-        __syncthreads();
-        stamp_at(1);
-
-        if (is_loader) {
-            // ================================ loader waves, fused ================================
-            __builtin_amdgcn_s_setprio(SVGF_LANE_LOADER_PRIO);
-            int it = 0;
-            for (int bo = b0; bo < b1; bo++, it++, dbg_it++) {
-                stamp(0);
-                // C: row bo+3 becomes a ring row (its slot was row bo-3's, dead since the last barrier)
-                if (bo + 3 <= b1 + 1) {
-                    THist th[YP];
-#pragma unroll
-                    for (int yp = 0; yp < YP; yp++) {
-                        nx3[yp].lds_off = (slot_of(bo + 3) * YP + yp) * ROWB + rec_of(lxi);
-                        t_stage_c1(nx3[yp], th[yp]);
-                    }
-                    stamp(1);
-#pragma unroll
-                    for (int yp = 0; yp < YP; yp++) if (lactive) t_stage_c2(nx3[yp], th[yp]);
-                }
-                stamp(2);
-                // B: row bo+4
-#pragma unroll
-                for (int yp = 0; yp < YP; yp++) { nx3[yp] = nx4[yp]; t_stage_b(nx3[yp]); }
-                stamp(3);
-                // A: row bo+5
-#pragma unroll
-                for (int yp = 0; yp < YP; yp++) {
-                    int lo, fl; unsigned p;
-                    t_describe(bo + 5, yp, lxi, 0, lactive && (bo + 5 <= b1 + 1), lo, p, fl);
-                    t_stage_a(nx4[yp], lo, p, fl);
-                }
-                stamp(5);
+            if (u >= 8 && !(u & 1)) stamp(1);
+            if (u >= 3 && (u - 3 < 4 || is_loader)) {   // C1: consistency, history request
+                int lo, fl; unsigned p;
+                describe_px(u - 3, lo, p, fl);
+                ac = ab;
+                t_stage_c1(ac, bb, rb, fl, p, cc);
+            }
+            if (u >= 8 && !(u & 1)) stamp(2);
+            if (u >= 2 && (u - 2 < 4 || is_loader)) {   // B: reprojection, consistency data of the bilinear quad
+                int lo, fl; unsigned p;
+                describe_px(u - 2, lo, p, fl);
+                ab = a1;
+                t_stage_b(ab, fl, bb, rb);
+            }
+            if (u >= 8 && !(u & 1)) stamp(3);
+            a1 = a0;
+            if (u < 4 || is_loader) {                   // A: primary loads
+                int lo, fl; unsigned p;
+                describe_px(u, lo, p, fl);
+                t_stage_a(a0, p);
+            }
+            if (u >= 8 && !(u & 1)) stamp(4);
+            if (u >= 7 && (u & 1)) {
+                if (u >= 9) stamp(5);
                 __syncthreads();
-                stamp(6);
-                ring_advance();
+                if (u == 7) stamp_at(1);
+                if (u >= 9) { stamp(6); ring_advance(); dbg_it++; }
+                if (!is_loader) break;
             }
-            return;
         }
+        if (is_loader) return;
     } else {
 #if SVGF_LANE_SPLIT_PROLOGUE
     // ---------------- prologue in two steps.  All 256 workgroups start at once and each wants five ring rows, a burst that
@@ -859,11 +885,13 @@ __global__ __launch_bounds__(NT) void k_atrous_lane(AtrousArgs a, LaneGeom gm, s
             r.C[i] = *reinterpret_cast<const v4f *>(rowp + i * PXB + 32);
         }
     };
-    auto load_geo = [&](GeoRow &r, int br) {
+    // (first_row: the forward row +1, whose three inner partners take their geometric term from the previous level with REUSE_IN:
+    // only their B slot — the luminance — is read)
+    auto load_geo = [&](GeoRow &r, int br, bool first_row = false) {
         const char *rowp = colbase + slot_of(br) * RSTR;
 #pragma unroll
         for (int i = 0; i < 5; i++) {
-            r.A[i] = *reinterpret_cast<const v4f *>(rowp + i * PXB);
+            if (!(REUSE_IN && first_row && i >= 1 && i <= 3)) r.A[i] = *reinterpret_cast<const v4f *>(rowp + i * PXB);
             r.B[i] = *reinterpret_cast<const v4f *>(rowp + i * PXB + 16);
         }
     };
@@ -871,7 +899,7 @@ __global__ __launch_bounds__(NT) void k_atrous_lane(AtrousArgs a, LaneGeom gm, s
         const char *rowp = colbase + slot_of(br) * RSTR;
 #pragma unroll
         for (int k = 0; k < 2; k++) {
-            r.A[k] = *reinterpret_cast<const v4f *>(rowp + (k + 3) * PXB);
+            if (!(REUSE_IN && k == 0)) r.A[k] = *reinterpret_cast<const v4f *>(rowp + (k + 3) * PXB);
             r.B[k] = *reinterpret_cast<const v4f *>(rowp + (k + 3) * PXB + 16);
             r.C[k] = *reinterpret_cast<const v4f *>(rowp + (k + 3) * PXB + 32);
             r.Cb[k] = *reinterpret_cast<const v4f *>(rowp + (1 - k) * PXB + 32);
@@ -895,15 +923,21 @@ __global__ __launch_bounds__(NT) void k_atrous_lane(AtrousArgs a, LaneGeom gm, s
 #pragma unroll
         for (int i = 0; i < 5; i++) accumulate(acc, r.C[i], w[i]);
     };
+    // (tin: REUSE_IN — the previous level's geometric terms {g(+1,0), g(-1,+1), g(0,+1), g(+1,+1)} of this centre: the forward row
+    // +1 takes partners -1, 0, +1 from it)
     auto do_geo = [&](Acc &acc, const GeoRow &r, int br, auto jtag, float (&F)[5], const v2f &c0, const v2f &c1,
-                      const v2f &c2, float lp, float kl, GeoRow *next, int br_next) {
+                      const v2f &c2, float lp, float kl, GeoRow *next, int br_next, const v4f &tin) {
         constexpr int j = decltype(jtag)::value;
+        constexpr bool TAKE = REUSE_IN && j == 1;
         const char *rowp = colbase + slot_of(br) * RSTR;
         v2f s2[5];
         v4f Cq[5];
         float lq[5];
 #pragma unroll
-        for (int i = 0; i < 5; i++) { s2[i] = geo(r.A[i], r.B[i], c0, c1, c2); lq[i] = r.B[i].z; }
+        for (int i = 0; i < 5; i++) {
+            if (!(TAKE && i >= 1 && i <= 3)) s2[i] = geo(r.A[i], r.B[i], c0, c1, c2);
+            lq[i] = r.B[i].z;
+        }
 #pragma unroll
         for (int i = 0; i < 5; i++) Cq[i] = *reinterpret_cast<const v4f *>(rowp + i * PXB + 32);
         if (next) load_geo(*next, br_next);        // the next forward row's geometry, once this row's is consumed
@@ -911,6 +945,7 @@ __global__ __launch_bounds__(NT) void k_atrous_lane(AtrousArgs a, LaneGeom gm, s
         float dn[5], dx[5];
 #pragma unroll
         for (int i = 0; i < 5; i++) {
+            if (TAKE && i >= 1 && i <= 3) continue;
             dn[i] = __builtin_amdgcn_sqrtf(s2[i].x);
             dx[i] = __builtin_amdgcn_sqrtf(s2[i].y);
         }
@@ -918,8 +953,13 @@ __global__ __launch_bounds__(NT) void k_atrous_lane(AtrousArgs a, LaneGeom gm, s
         float e[5], w[5];
 #pragma unroll
         for (int i = 0; i < 5; i++) {
-            float t = fmaf(dn[i], kn, nlh(i - 2, j));
-            t = fmaf(dx[i], kx, t);
+            float t;
+            if (TAKE && i >= 1 && i <= 3) {
+                t = (i == 1 ? tin.y : (i == 2 ? tin.z : tin.w)) + nlh(i - 2, j);
+            } else {
+                t = fmaf(dn[i], kn, nlh(i - 2, j));
+                t = fmaf(dx[i], kx, t);
+            }
             F[i] = t;
             e[i] = fmaf(fabsf(lq[i] - lp), kl, t);
         }
@@ -978,7 +1018,11 @@ __global__ __launch_bounds__(NT) void k_atrous_lane(AtrousArgs a, LaneGeom gm, s
     // iteration, in front of its output stage, so that the LDS round trip is over when the barrier opens — after the barrier
     // all eight waves ask at once, with nothing else to issue (-0.7 .. -1.3 us on that level).  At 164 VGPRs the carried
     // registers cost the other variants what the prefetch brings (profiles/r03_ab_lane_centre_prefetch.log): they read at the top.
+#ifdef SVGF_LANE_PREFETCH_ALL
+    constexpr bool PREFETCH_CENTRE = true;
+#else
     constexpr bool PREFETCH_CENTRE = !HASVAR;
+#endif
     struct Centre { v4f A, B; float c0v, c2v; float up[3], dn[3]; };
     const int off_c = (xph * MP + mcol) * PXB + 44;      // this lane's own column, like off_l / off_r
     auto prefetch_centre = [&](Centre &cn, int bo) {
@@ -1005,7 +1049,21 @@ __global__ __launch_bounds__(NT) void k_atrous_lane(AtrousArgs a, LaneGeom gm, s
             }
         } else { cn.c0v = 0.0f; cn.c2v = 0.0f; }
     };
-    auto body = [&](int bo, int it, bool careful, Centre &cen) {
+    // the previous level's geometric terms of this lane's centre in lattice row br (halo lanes and lanes right of / below the
+    // image too: their forward terms are their neighbours' backward terms; a clamped address keeps what they read finite, and
+    // an out-of-image pixel has weight 0 whatever its terms are)
+    // The terms plane is laid out for the CONSUMER's lanes: [row][x mod S'][x / S'] with S' the consumer's step (M' = a.t_m lattice
+    // columns per phase): the 64 lanes of a consumer wave — consecutive lattice columns of one x-phase — read 1 KB of consecutive
+    // bytes, and a producer wave (step S'/2: its even lanes belong to consumer phase ph, its odd lanes to ph + S'/2) writes two
+    // runs of 512 consecutive bytes.  (Pixel-major, the first version, had every lane of both on its own cache line from step 8
+    // on: the levels got 5-20 % SLOWER, profiles/r04_ab_reuse_pixel_major.log.)
+    auto fetch_terms = [&](int br) -> v4f {
+        const int yc = min(yphase + (br << LOG2S), H - 1), xc = min(max(x, 0), W - 1);
+        const unsigned idx = ((unsigned)(yc << LOG2S) + (unsigned)(xc & (S - 1))) * (unsigned)a.t_m + (unsigned)(xc >> LOG2S);
+        return *reinterpret_cast<const v4f *>(reinterpret_cast<const char *>(a.tin) + idx * 16u);
+    };
+    // tcur: REUSE_IN — the previous level's four geometric terms of this iteration's centre (fetched one iteration ahead)
+    auto body = [&](int bo, int it, bool careful, Centre &cen, v4f &tcur) {
         stamp(0);
         constexpr int PR[7] = { SVGF_LANE_PRIO };
         if constexpr (PR[0] == PR[3]) __builtin_amdgcn_s_setprio(PR[0]);
@@ -1020,7 +1078,7 @@ __global__ __launch_bounds__(NT) void k_atrous_lane(AtrousArgs a, LaneGeom gm, s
         if constexpr (CHUNKED) {
             // the loader threads computed the blurred variance of this row from the variance plane (see vblur_store)
             const float bvar = blur[(it & 1) * BLUR_BUF + xph * M + mcol];
-            if (flip) load_geo(g1, bo + 1); else load_col(r0, bo - 2);
+            if (flip) load_geo(g1, bo + 1, true); else load_col(r0, bo - 2);
             var = a.blur_variance ? bvar : C.w;
         } else {
         float m0, m1, m2, p0, p1, p2;
@@ -1032,7 +1090,7 @@ __global__ __launch_bounds__(NT) void k_atrous_lane(AtrousArgs a, LaneGeom gm, s
             p0 = bl[BLUR_ROW + be_l]; p1 = bl[BLUR_ROW + be_c]; p2 = bl[BLUR_ROW + be_r];
         }
         const float c0v = cen.c0v, c2v = cen.c2v;
-        if (flip) load_geo(g1, bo + 1); else load_col(r0, bo - 2);       // the first tap row of this wave's stage order
+        if (flip) load_geo(g1, bo + 1, true); else load_col(r0, bo - 2);       // the first tap row of this wave's stage order
         {   // centre variance: 3x3 gaussian with out-of-image taps dropped and renormalised (:102-118)
             const float wr_m = (y - 1 >= 0) ? 0.25f : 0.0f, wr_p = (y + 1 < H) ? 0.25f : 0.0f;
             const float wc_l = (x - 1 >= 0) ? 0.25f : 0.0f, wc_r = (x + 1 < W) ? 0.25f : 0.0f;
@@ -1058,6 +1116,7 @@ __global__ __launch_bounds__(NT) void k_atrous_lane(AtrousArgs a, LaneGeom gm, s
         acc.rg = v2f{w0 * C.x, w0 * C.y};
         acc.bv = v2f{w0 * C.z, (w0 * w0) * C.w};
 
+        v4f tout_v = v4f{0.0f, 0.0f, 0.0f, 0.0f};             // REUSE_OUT: g(+2,0), g(-2,+2), g(0,+2), g(+2,+2) of this centre
         if (careful) {
             acc.rg = v2f{0.0f, 0.0f}; acc.bv = v2f{0.0f, 0.0f}; acc.ww = v2f{0.0f, 0.0f};
 #pragma unroll 1
@@ -1076,15 +1135,25 @@ __global__ __launch_bounds__(NT) void k_atrous_lane(AtrousArgs a, LaneGeom gm, s
                     e = fmaf(dn, kn, e);
                     e = fmaf(dx, kx, e);
                     accumulate(acc, Cq, __builtin_amdgcn_exp2f(-e));
+                    if constexpr (REUSE_OUT) {
+                        // the next level's workgroups that do not stage the non-finite texel read these terms like any others
+                        const float g = fmaf(dx, kx, dn * kn);
+                        if (j == 0 && i == 2) tout_v.x = g;
+                        if (j == 2 && i == -2) tout_v.y = g;
+                        if (j == 2 && i == 0) tout_v.z = g;
+                        if (j == 2 && i == 2) tout_v.w = g;
+                    }
                 }
             }
         } else {
         // Each row's first LDS reads are issued one row ahead (in front of the previous row's fence).
         // own row: the two right-hand neighbours are evaluated, the two left-hand ones arrive from lanes x-1, x-2
+        float tf[2];                                          // own row's forward terms (+1, 0), (+2, 0)
         auto do_own = [&](const OwnRow &r2) {
-            float e[4], tf[2];
+            float e[4];
 #pragma unroll
             for (int k = 0; k < 2; k++) {
+                if (REUSE_IN && k == 0) { tf[0] = tcur.x + nlh(1, 0); continue; }
                 const v2f s2 = geo(r2.A[k], r2.B[k], c0, c1, c2);
                 const float dn = __builtin_amdgcn_sqrtf(s2.x), dx = __builtin_amdgcn_sqrtf(s2.y);
                 const float t = fmaf(dn, kn, nlh(k + 1, 0));
@@ -1118,30 +1187,30 @@ __global__ __launch_bounds__(NT) void k_atrous_lane(AtrousArgs a, LaneGeom gm, s
             row_fence(acc);
             do_col(acc, r1, pF1, lp, kl, lp1);
             __builtin_amdgcn_s_setprio(PR[1]);              // ~1/4 of the row's work done
-            load_geo(g1, bo + 1);
+            load_geo(g1, bo + 1, true);
             row_fence(acc);
             stamp(2);
             do_own(r2);
             stamp(3);
             row_fence(acc);
             // forward rows: evaluate, use, and keep for the partners
-            do_geo(acc, g1, bo + 1, std::integral_constant<int, 1>{}, F1, c0, c1, c2, lp, kl, nullptr, 0);
+            do_geo(acc, g1, bo + 1, std::integral_constant<int, 1>{}, F1, c0, c1, c2, lp, kl, nullptr, 0, tcur);
             __builtin_amdgcn_s_setprio(PR[2]);              // ~2/3
             row_fence(acc);
             GeoRow g2;
             load_geo(g2, bo + 2);
-            do_geo(acc, g2, bo + 2, std::integral_constant<int, 2>{}, F2, c0, c1, c2, lp, kl, nullptr, 0);
+            do_geo(acc, g2, bo + 2, std::integral_constant<int, 2>{}, F2, c0, c1, c2, lp, kl, nullptr, 0, tcur);
             row_fence(acc);
         } else {
             // ---- stage order B (waves 4-7, which share their SIMDs with waves 0-3): forward rows, own row, backward
             //      rows.  The forward rows are VALU-heavy, the backward rows LDS-heavy: with the two waves of a SIMD in
             //      opposite orders the two kinds of work overlap instead of queueing up behind the same pipe. ----
-            do_geo(acc, g1, bo + 1, std::integral_constant<int, 1>{}, F1, c0, c1, c2, lp, kl, nullptr, 0);
+            do_geo(acc, g1, bo + 1, std::integral_constant<int, 1>{}, F1, c0, c1, c2, lp, kl, nullptr, 0, tcur);
             __builtin_amdgcn_s_setprio(PR[4]);              // ~1/3
             row_fence(acc);
             GeoRow g2;
             load_geo(g2, bo + 2);
-            do_geo(acc, g2, bo + 2, std::integral_constant<int, 2>{}, F2, c0, c1, c2, lp, kl, nullptr, 0);
+            do_geo(acc, g2, bo + 2, std::integral_constant<int, 2>{}, F2, c0, c1, c2, lp, kl, nullptr, 0, tcur);
             __builtin_amdgcn_s_setprio(PR[5]);              // ~2/3
             OwnRow r2;
             load_own(r2, bo);
@@ -1160,6 +1229,7 @@ __global__ __launch_bounds__(NT) void k_atrous_lane(AtrousArgs a, LaneGeom gm, s
             row_fence(acc);
         }
         publish(F1, F2);
+        if constexpr (REUSE_OUT) tout_v = v4f{tf[1] - nlh(2, 0), F2[0] - nlh(-2, 2), F2[2] - nlh(0, 2), F2[4] - nlh(2, 2)};
         }
 
         stamp(4);
@@ -1180,7 +1250,14 @@ __global__ __launch_bounds__(NT) void k_atrous_lane(AtrousArgs a, LaneGeom gm, s
             if (a.dst) a.dst[p] = make_float4(o0, o1, o2, ov);
             if (a.var_dst) a.var_dst[(unsigned)(y + 1) * (unsigned)(W + 2) + (unsigned)(x + 1)] = ov;
             if (a.out_rgb) { float *o = a.out_rgb + 3u * p; o[0] = o0; o[1] = o1; o[2] = o2; }
+            if constexpr (REUSE_OUT) {       // consumer's layout: step 2S, a.t_m_out lattice columns per phase
+                const unsigned idx = ((unsigned)(y << (LOG2S + 1)) + (unsigned)(x & (2 * S - 1))) * (unsigned)a.t_m_out + (unsigned)(x >> (LOG2S + 1));
+                *reinterpret_cast<v4f *>(reinterpret_cast<char *>(a.tout) + idx * 16u) = tout_v;
+            }
         }
+        // (requesting them at the TOP of the iteration instead, in front of the output stores whose acknowledgements an in-order
+        // vmcnt otherwise waits for, was measured: worse, profiles/r04_ab_reuse_early_load.log)
+        if constexpr (REUSE_IN) tcur = fetch_terms(bo + 1);
         if constexpr (PREFETCH_CENTRE) cen = nxt;
         lp2 = lp1; lp1 = lp;
     };
@@ -1188,8 +1265,10 @@ __global__ __launch_bounds__(NT) void k_atrous_lane(AtrousArgs a, LaneGeom gm, s
     int it = 0;
     Centre cen;
     if constexpr (PREFETCH_CENTRE) prefetch_centre(cen, b0);
+    v4f tcur = v4f{0.0f, 0.0f, 0.0f, 0.0f};
+    if constexpr (REUSE_IN) tcur = fetch_terms(b0);
     for (int bo = b0; bo < b1; bo++, it++) {
-        body(bo, it, *nan_seen != 0, cen);
+        body(bo, it, *nan_seen != 0, cen, tcur);
         stamp(5);
         __syncthreads();
         stamp(6);
@@ -1225,7 +1304,7 @@ inline long lane_segment_search(int n_strips, int S, int nb_max, int n_cu, int *
     return best_cost;
 }
 
-template <int LOG2S, bool HASVAR, int LOG2P = LOG2S, int LOG2Y = 0, bool FUSED = false>
+template <int LOG2S, bool HASVAR, int LOG2P = LOG2S, int LOG2Y = 0, bool FUSED = false, int REUSE = 0>
 hipError_t launch_lane_cfg(const AtrousArgs &a, hipStream_t s, const TemporalArgs *ta = nullptr)
 {
     constexpr int S = 1 << LOG2S, P = 1 << LOG2P, YP = 1 << LOG2Y, M = LOUT * (NWC / (P * YP)) + 4, MP = (P == 4) ? M + 2 : ((M * 12 % 64 == 0) ? M + 1 : M), BM = (BW + S - 1) / S;
@@ -1234,7 +1313,7 @@ hipError_t launch_lane_cfg(const AtrousArgs &a, hipStream_t s, const TemporalArg
     static_assert(kLds <= 160 * 1024, "LDS budget");
     static SvgfLaunchCache cache;
     int dev_id = 0;
-    if (hipError_t e = cache.init(reinterpret_cast<const void *>(&k_atrous_lane<LOG2S, HASVAR, LOG2P, LOG2Y, FUSED>), (int)lds, &dev_id); e != hipSuccess) return e;
+    if (hipError_t e = cache.init(reinterpret_cast<const void *>(&k_atrous_lane<LOG2S, HASVAR, LOG2P, LOG2Y, FUSED, REUSE>), (int)lds, &dev_id); e != hipSuccess) return e;
     const int n_cu = cache.n_cu[dev_id];
     LaneGeom gm;
     gm.n_strips = lane_strip_count(a.W, S, YP);
@@ -1260,8 +1339,8 @@ hipError_t launch_lane_cfg(const AtrousArgs &a, hipStream_t s, const TemporalArg
         gm.dbg = dbg_buf; gm.dbg_block = atoi(dbg_env);
     }
 #endif
-    if constexpr (FUSED) hipLaunchKernelGGL((k_atrous_lane<LOG2S, HASVAR, LOG2P, LOG2Y, true>), dim3(nblocks), dim3(NT), lds, s, a, gm, *ta);
-    else hipLaunchKernelGGL((k_atrous_lane<LOG2S, HASVAR, LOG2P, LOG2Y, false>), dim3(nblocks), dim3(NT), lds, s, a, gm, LaneNoTemporal{});
+    if constexpr (FUSED) hipLaunchKernelGGL((k_atrous_lane<LOG2S, HASVAR, LOG2P, LOG2Y, true, REUSE>), dim3(nblocks), dim3(NT), lds, s, a, gm, *ta);
+    else hipLaunchKernelGGL((k_atrous_lane<LOG2S, HASVAR, LOG2P, LOG2Y, false, REUSE>), dim3(nblocks), dim3(NT), lds, s, a, gm, LaneNoTemporal{});
 #ifdef SVGF_LANE_TIMELINE
     if (dbg_env) {
         static int skip = getenv("SVGF_LANE_DBG_SKIP") ? atoi(getenv("SVGF_LANE_DBG_SKIP")) : 0, prints = 0;
@@ -1280,8 +1359,8 @@ hipError_t launch_lane_cfg(const AtrousArgs &a, hipStream_t s, const TemporalArg
                             h[(w * 16) * 8 + 0] - h[(w * 16) * 8 + 7]);
                 for (int it = 0; it < 8 && h[(w * 16 + it) * 8]; it++) {
                     unsigned long long *t = &h[(w * 16 + it) * 8];
-                    if (w >= NWC && FUSED) fprintf(stderr, "  loader %2d it %2d: t0=%6llu C1 (resolve, issue history) %5llu C2 (wait, blend, commit) %6llu B %5llu A %5llu barrier %5llu\n", w, it,
-                                                   t[0] - h[0], t[1] - t[0], t[2] - t[1], t[3] - t[2], t[5] - t[3], t[6] - t[5]);
+                    if (w >= NWC && FUSED) fprintf(stderr, "  loader %2d it %2d: t0=%6llu first pixel: C2 (blend, commit) %5llu C1 (consistency, history request) %5llu B %5llu A %5llu | second pixel %6llu | barrier %5llu\n", w, it,
+                                                   t[0] - h[0], t[1] - t[0], t[2] - t[1], t[3] - t[2], t[4] - t[3], t[5] - t[4], t[6] - t[5]);
                     else if (w >= NWC) fprintf(stderr, "  loader %2d it %2d: t0=%6llu work %6llu barrier %5llu\n", w, it, t[0] - h[0], t[5] - t[0], t[6] - t[5]);
                     else fprintf(stderr, "  wave %2d it %2d: t0=%6llu centre %5llu back rows %5llu own %5llu fwd rows %5llu out %5llu barrier %5llu\n", w, it,
                                  t[0] - h[0], t[1] - t[0], t[2] - t[1], t[3] - t[2], t[4] - t[3], t[5] - t[4], t[6] - t[5]);

@@ -660,7 +660,8 @@ long strip_segment_search(int n_strips, int S, int nb_max, int ROWS, int capacit
         // (phase, segment) groups are dealt round-robin to the 8 XCDs (blockIdx % 8), all strips of a group to the same
         // XCD: the busiest XCD, with ceil(groups / 8) groups, sets the number of rounds
         const long blocks_xcd = (long)n_strips * ((S * segs_l + 7) / 8);
-        const long rounds = (blocks_xcd + capacity / 8 - 1) / (capacity / 8);
+        const long cap_xcd = capacity / 8 > 0 ? capacity / 8 : 1;        // (a device with fewer than 8 CUs: one workgroup per "XCD" at a time)
+        const long rounds = (blocks_xcd + cap_xcd - 1) / cap_xcd;
         const long cost = rounds * ((L + ROWS - 1) / ROWS * ROWS + fixed_rows);
         if (best_cost < 0 || cost <= best_cost) { best_cost = cost; best_L = L; }   // ties: fewer, longer workgroups
     }

@@ -67,6 +67,14 @@ struct AtrousArgs {
     int modulate;
     const float *var;         // optional 4-B/px variance plane holding src[].w (pre-blur neighbourhood reads), may be null
     float *var_dst;           // optional 4-B/px variance plane written next to dst, may be null
+    // cross-level reuse of the geometric terms (lane kernel only, svgf_atrous_lane_impl.h REUSE): per pixel {g(+1,0), g(-1,+1),
+    // g(0,+1), g(+1,+1)} in units of THIS level's step, g = kn |dn| + kx |dx|, written by the previous level (whose step is half
+    // this one's and whose sigma_n / sigma_x are the same); tout: the same for the next level.  Either may be null.
+    // Layout: element ((y * S' + x mod S') * M' + x / S') with S' the CONSUMING level's step and M' = ceil(W / S') (t_m for tin,
+    // t_m_out for tout): consecutive lanes of a consumer wave read consecutive elements.  Plane size (W + 64) * H elements.
+    const float4 *tin;
+    float4 *tout;
+    int t_m, t_m_out;
 };
 
 struct TemporalArgs {
@@ -100,6 +108,7 @@ hipError_t launch_atrous_strip(const AtrousArgs &a, hipStream_t s);    // LDS st
 bool       atrous_strip_supported(const AtrousArgs &a);
 double     atrous_strip_estimate_us(const AtrousArgs &a, int n_cu);   // launch-geometry cost model (automatic kernel choice)
 hipError_t launch_atrous_lane(const AtrousArgs &a, hipStream_t s);     // lane-marching kernel, symmetric terms shared by DPP (steps 1 .. 32)
+hipError_t launch_atrous_lane_reuse(const AtrousArgs &a, hipStream_t s);   // the same with a.tin / a.tout (cross-level reuse of geometric terms)
 bool       atrous_lane_supported(const AtrousArgs &a);
 double     atrous_lane_estimate_us(const AtrousArgs &a, int n_cu);
 // temporal pass fused into the first level (step 2): the lane kernel's loader waves accumulate the pixels they stage

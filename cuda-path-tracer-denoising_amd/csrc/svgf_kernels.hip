@@ -29,8 +29,10 @@ __device__ __forceinline__ int reproj_valid(const TemporalArgs &a, float qx, flo
 {
     const int q = svgf_tap_index(a, qx, qy);                          // bounds (:173-176); NaN coordinate: defined as invalid
     if (q < 0) return -1;
+    const int gq = a.gid_prev[q];
+    if (gq == -1 || gq != gid) return -1;                             // (before the normal is fetched: most rejected taps end here)
     const float *n = a.nrm_prev + 3 * (size_t)q;
-    return svgf_tap_consistent(a.gid_prev[q], n[0], n[1], n[2], gid, nx, ny, nz) ? q : -1;
+    return svgf_normals_close(n[0], n[1], n[2], nx, ny, nz) ? q : -1;
 }
 
 // SvgfParams::reproj_position_tol (f4 extension): the tap's previous-frame world position must lie within tol of the

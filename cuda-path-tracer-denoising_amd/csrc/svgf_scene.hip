@@ -242,25 +242,33 @@ static int scene_render_impl(int device, void *out_rgb_dev, void *out_gbuffer_de
     const size_t b_ta = sizeof(float) * 3 * (size_t)(n_tris > 0 ? n_tris : 1);
     const size_t b_tt = b_ti, b_td = sizeof(int) * 3 * (size_t)(n_tex > 0 ? n_tex : 1);
     const size_t o_tt = b_g + b_gi + b_t + b_ti + b_ta, o_td = o_tt + b_tt, o_tex = (o_td + b_td + 15) & ~(size_t)15;
+    // The uploads run on a library-owned stream `up`, not on the caller's: the host waits for THEM (the arrays are the caller's,
+    // usually pageable, often temporaries of a binding, and must have been read when this function returns) without waiting for
+    // whatever else is queued on `s` — the previous frame's whole denoise, typically — and without a host synchronisation on a
+    // stream that may be under capture.  The kernel and the release of the staging memory stay asynchronous on `s`.
+    static hipStream_t up_streams[64];
+    static std::once_flag up_once[64];
+    const int dslot = (device >= 0 && device < 64) ? device : 0;
+    std::call_once(up_once[dslot], [&]() { if (hipStreamCreateWithFlags(&up_streams[dslot], hipStreamNonBlocking) != hipSuccess) up_streams[dslot] = nullptr; });
+    hipStream_t up = up_streams[dslot];
+    if (!up) return SVGF_ERR_HIP;
     char *d = nullptr;
-    if (hipMallocAsync(reinterpret_cast<void **>(&d), o_tex + b_tex, s) != hipSuccess) return SVGF_ERR_OOM;
+    if (hipMallocAsync(reinterpret_cast<void **>(&d), o_tex + b_tex, up) != hipSuccess) return SVGF_ERR_OOM;
     bool ok = true;
-    if (n_geoms > 0) ok = ok && hipMemcpyAsync(d, geoms, sizeof(SvgfSceneGeom) * (size_t)n_geoms, hipMemcpyHostToDevice, s) == hipSuccess;
-    if (n_geoms > 0 && geom_ids) ok = ok && hipMemcpyAsync(d + b_g, geom_ids, sizeof(int) * (size_t)n_geoms, hipMemcpyHostToDevice, s) == hipSuccess;
+    if (n_geoms > 0) ok = ok && hipMemcpyAsync(d, geoms, sizeof(SvgfSceneGeom) * (size_t)n_geoms, hipMemcpyHostToDevice, up) == hipSuccess;
+    if (n_geoms > 0 && geom_ids) ok = ok && hipMemcpyAsync(d + b_g, geom_ids, sizeof(int) * (size_t)n_geoms, hipMemcpyHostToDevice, up) == hipSuccess;
     if (n_tris > 0) {
-        ok = ok && hipMemcpyAsync(d + b_g + b_gi, tris, sizeof(float) * 24 * (size_t)n_tris, hipMemcpyHostToDevice, s) == hipSuccess;
-        ok = ok && hipMemcpyAsync(d + b_g + b_gi + b_t, tri_ids, sizeof(int) * (size_t)n_tris, hipMemcpyHostToDevice, s) == hipSuccess;
-        ok = ok && hipMemcpyAsync(d + b_g + b_gi + b_t + b_ti, tri_albedo, sizeof(float) * 3 * (size_t)n_tris, hipMemcpyHostToDevice, s) == hipSuccess;
+        ok = ok && hipMemcpyAsync(d + b_g + b_gi, tris, sizeof(float) * 24 * (size_t)n_tris, hipMemcpyHostToDevice, up) == hipSuccess;
+        ok = ok && hipMemcpyAsync(d + b_g + b_gi + b_t, tri_ids, sizeof(int) * (size_t)n_tris, hipMemcpyHostToDevice, up) == hipSuccess;
+        ok = ok && hipMemcpyAsync(d + b_g + b_gi + b_t + b_ti, tri_albedo, sizeof(float) * 3 * (size_t)n_tris, hipMemcpyHostToDevice, up) == hipSuccess;
     }
     if (n_tex > 0) {
-        ok = ok && hipMemcpyAsync(d + o_tt, tri_tex, sizeof(int) * (size_t)n_tris, hipMemcpyHostToDevice, s) == hipSuccess;
-        ok = ok && hipMemcpyAsync(d + o_td, tex_desc, sizeof(int) * 3 * (size_t)n_tex, hipMemcpyHostToDevice, s) == hipSuccess;
-        ok = ok && hipMemcpyAsync(d + o_tex, tex_data, n_texbytes, hipMemcpyHostToDevice, s) == hipSuccess;
+        ok = ok && hipMemcpyAsync(d + o_tt, tri_tex, sizeof(int) * (size_t)n_tris, hipMemcpyHostToDevice, up) == hipSuccess;
+        ok = ok && hipMemcpyAsync(d + o_td, tex_desc, sizeof(int) * 3 * (size_t)n_tex, hipMemcpyHostToDevice, up) == hipSuccess;
+        ok = ok && hipMemcpyAsync(d + o_tex, tex_data, n_texbytes, hipMemcpyHostToDevice, up) == hipSuccess;
     }
-    // the host arrays are the caller's (usually pageable, often temporaries of a binding): they have been read completely
-    // when this function returns — the uploads are waited for here, the kernel behind them stays asynchronous
-    ok = ok && hipStreamSynchronize(s) == hipSuccess;
-    if (!ok) { (void)hipFreeAsync(d, s); return SVGF_ERR_HIP; }
+    ok = ok && hipStreamSynchronize(up) == hipSuccess;      // allocation and uploads complete: `s` may use the memory without an event
+    if (!ok) { (void)hipFreeAsync(d, up); return SVGF_ERR_HIP; }
     SceneArgs a;
     for (int c = 0; c < 3; c++) { a.right[c] = cam->right[c]; a.up[c] = cam->up[c]; a.view[c] = cam->view[c]; a.o[c] = cam->position[c]; a.light[c] = light[c]; }
     a.plx = sp->pixel_length[0]; a.ply = sp->pixel_length[1];

@@ -59,11 +59,22 @@ __device__ __forceinline__ int svgf_tap_index(const TemporalArgs &a, float qx, f
     return (int)qx + (int)qy * a.W;
 }
 
-// consistency part of isReprjValid (:177-180) on the tap's previous-frame geomId / normal
+// consistency part of isReprjValid (:177-180) on the tap's previous-frame geomId / normal.  `distance(n_prev, n_cur) > 1e-1f`
+// is evaluated on the SQUARED distance: sqrtf is correctly rounded and monotonic, so sqrtf(s) > 0.1f  <=>  s > 0x3c23d70b (the
+// largest float whose root still rounds to <= 0.1f; found by stepping through the floats around 0.01, tools/experiments/
+// temporal_branch_free_validity_32bit_offsets.patch carried the same constant in round 1).  NaN compares false either way, i.e.
+// a NaN distance PASSES, as in the reference.  Branch-free: the fused kernel evaluates it for nine taps per pixel.
+__device__ __forceinline__ bool svgf_normals_close(float nqx, float nqy, float nqz, float nx, float ny, float nz)
+{
+#pragma clang fp contract(off)
+    const float dx = nx - nqx, dy = ny - nqy, dz = nz - nqz;          // glm::distance(a, b) = length(b - a): b is the current normal
+    float s = dx * dx + dy * dy;
+    s = s + dz * dz;
+    return !(s > __uint_as_float(0x3c23d70bu));
+}
 __device__ __forceinline__ bool svgf_tap_consistent(int gq, float nqx, float nqy, float nqz, int gid, float nx, float ny, float nz)
 {
-    if (gq == -1 || gq != gid) return false;
-    return !(svgf_dist3_strict(nqx, nqy, nqz, nx, ny, nz) > 1e-1f);
+    return (gq != -1) & (gq == gid) & svgf_normals_close(nqx, nqy, nqz, nx, ny, nz);
 }
 
 // bilinear weights of the four taps (0,0) (1,0) (0,1) (1,1) (:237-240)

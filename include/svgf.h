@@ -224,7 +224,9 @@ int svgf_synth_render(int device, void *out_rgb_dev, void *out_gbuffer_dev, int 
  *   normal, position: packed float3 per pixel; geom_id: int per pixel (-1 = miss); albedo: packed float3 per pixel holding
  *   albedo * ialbedo (only read on the last level when sepcolor && addcolor; may be left unwritten otherwise).
  * The pointers are valid for exactly ONE svgf_denoise_planar call on this context (the planes rotate with the history: ask
- * again for the next frame); producer and svgf_denoise_planar must be ordered on the same stream.  Results are bit-identical
+ * again for the next frame); producer and svgf_denoise_planar must be ordered on the same stream.  svgf_reset between
+ * svgf_planar_gbuffer and svgf_denoise_planar is allowed: it clears both plane sets (so fill the planes AFTER the reset) but
+ * does not change which set the pointers name.  Results are bit-identical
  * to svgf_denoise on the same texels (tests/test_planar_inputs.py).  AoS and planar frames may alternate on one context. */
 typedef struct SvgfPlanarGBuffer {
     float *normal;

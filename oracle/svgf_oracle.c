@@ -434,6 +434,7 @@ void svgf_oracle_view_matrix(const SvgfCamera *cam, float out[16])
 
 struct oracle_ctx {
     int W, H, nthreads, variance_mode;
+    long frames;                        /* svgf_oracle_denoise calls since create: the planes hold state once it is > 0 */
     float view_prev[16];                /* static glm::mat4, identity by default ctor, never reset (:15) */
     float *temp[2];                     /* vec3 ping-pong (:27) */
     int   *history_length, *history_length_update;
@@ -475,11 +476,15 @@ static void free_planes(oracle_ctx *c)
     free(c->moment_history); free(c->moment_acc); free(c->color_history); free(c->color_acc);
     free(c->gbuffer_prev); free(c->variance); free(c->variance_tmp); free(c->variance_temporal);
     free(c->in_local); free(c->g_local);
+    c->temp[0] = c->temp[1] = NULL; c->history_length = c->history_length_update = NULL;
+    c->moment_history = c->moment_acc = NULL; c->color_history = c->color_acc = NULL;
+    c->gbuffer_prev = NULL; c->variance = c->variance_tmp = c->variance_temporal = NULL;
+    c->in_local = NULL; c->g_local = NULL;
 }
 
 /* malloc, then zeroed in parallel by c->nthreads threads: the state keeps the reference's all-zero start (denoiseInit's
  * cudaMemset, :37-59) and every page is first touched by the thread that owns its rows */
-static void alloc_planes(oracle_ctx *c)
+static int alloc_planes(oracle_ctx *c)      /* 0, or -1 when a plane could not be allocated (everything is freed again) */
 {
     const size_t W = (size_t)c->W, n = W * c->H;
     const int H = c->H, nt = c->nthreads;
@@ -497,21 +502,29 @@ static void alloc_planes(oracle_ctx *c)
     c->variance_temporal = (float *)malloc(n * sizeof(float));
     c->in_local = (float *)malloc(n * 3 * sizeof(float));
     c->g_local = (SvgfGBufferTexel *)malloc(n * sizeof(SvgfGBufferTexel));
+    if (!c->temp[0] || !c->temp[1] || !c->history_length || !c->history_length_update || !c->moment_history || !c->moment_acc ||
+        !c->color_history || !c->color_acc || !c->gbuffer_prev || !c->variance || !c->variance_tmp || !c->variance_temporal ||
+        !c->in_local || !c->g_local) {
+        free_planes(c);
+        return -1;
+    }
     par_zero(c->temp[0], W * 3 * sizeof(float), H, nt);
     par_zero(c->temp[1], W * 3 * sizeof(float), H, nt);
     par_zero(c->variance_tmp, W * sizeof(float), H, nt);
     par_zero(c->in_local, W * 3 * sizeof(float), H, nt);
     par_zero(c->g_local, W * sizeof(SvgfGBufferTexel), H, nt);
     zero_history(c);
+    return 0;
 }
 
 oracle_ctx *svgf_oracle_create(int W, int H)
 {
     if (W <= 0 || H <= 0) return NULL;
     oracle_ctx *c = (oracle_ctx *)calloc(1, sizeof(*c));
+    if (!c) return NULL;
     c->W = W; c->H = H; c->nthreads = 1; c->variance_mode = ORACLE_VARIANCE_SNAPSHOT;
     for (int k = 0; k < 16; k++) c->view_prev[k] = (k % 5 == 0) ? 1.0f : 0.0f;
-    alloc_planes(c);
+    if (alloc_planes(c) != 0) { free(c); return NULL; }
     return c;
 }
 
@@ -532,8 +545,12 @@ void svgf_oracle_set_threads(oracle_ctx *c, int n)
     n = n > 0 ? n : 1;
     if (n == c->nthreads) return;
     c->nthreads = n;
-    free_planes(c);
-    alloc_planes(c);
+    /* The planes are first-touched by the threads that will work on them (alloc_planes): re-placing them for the new thread
+     * count is only done while they hold no state, i.e. before the first frame; later the count changes and the pages stay. */
+    if (c->frames == 0) {
+        free_planes(c);
+        if (alloc_planes(c) != 0) { c->nthreads = 1; (void)alloc_planes(c); }
+    }
 }
 void svgf_oracle_set_variance_mode(oracle_ctx *c, int m) { if (c) c->variance_mode = m; }
 
@@ -554,6 +571,8 @@ int svgf_oracle_denoise(oracle_ctx *c, float *out, const float *in, const SvgfGB
     const int W = c->W, H = c->H;
     const size_t n = (size_t)W * H;
     const int nt = c->nthreads;
+    if (!c->in_local) return -1;        /* the planes could not be allocated */
+    c->frames++;
     /* inputs next to the threads that read them (taps reach at most 64 rows beyond a thread's own block) */
     par_copy(c->in_local, in, (size_t)W * 3 * sizeof(float), H, nt);
     par_copy(c->g_local, g, (size_t)W * sizeof(SvgfGBufferTexel), H, nt);

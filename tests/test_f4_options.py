@@ -100,25 +100,3 @@ def test_hip_matches_oracle_with_f4_options(pkg, orc, W, H, moving, tol, K):
         assert relerr(d.read_state(3), o.read_state(3)).max() <= 2e-4, f"variance after the temporal pass, frame {f}"      # flat: no growth allowance
         assert relerr(got, ref).max() <= 1e-4, f"frame {f}: {relerr(got, ref).max():.3e}"
     d.free(); o.free()
-
-
-@pytest.mark.gpu
-def test_f4_options_with_overlap_are_bit_identical(pkg):
-    import torch
-    W, H, N = 640, 360, 6
-    frames = [pkg.synth.render_frame(W, H, f, seed=37, moving=True) for f in range(3)]
-    tin = [torch.from_numpy(f[0]).cuda() for f in frames]
-    tg = [torch.from_numpy(f[1].view(np.uint8).reshape(-1)).cuda() for f in frames]
-    res = {}
-    for ready in (0, 1):
-        p = _params(pkg, W, H, tol=0.05, K=4).set(inputs_ready=ready)
-        d = pkg.Denoiser(W, H, 0)
-        outs = [torch.empty((H, W, 3), dtype=torch.float32, device="cuda") for _ in range(N)]
-        torch.cuda.synchronize()
-        for k in range(N):
-            d.denoise(outs[k], tin[k % 3], tg[k % 3], frames[k % 3][2], p, stream=torch.cuda.current_stream())
-        d.sync()
-        res[ready] = [o.cpu().numpy() for o in outs]
-        d.free()
-    for k in range(N):
-        assert np.array_equal(res[0][k], res[1][k]), f"frame {k}"

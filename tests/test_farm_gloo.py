@@ -106,3 +106,31 @@ def test_bench_distributed_branch_runs_with_one_rank_on_rccl():
     assert line["metric"].startswith("SVGF Mpixels/s (full pipeline) at 1080p") and line["unit"] == "Mpixels/s"
     assert line["n_gpus"] == 1 and line["steps"] == 5 and line["scaling"] == "weak" and line["value"] > 100
     assert 0 < line["roofline"]["frac"] < 1 and line["config"]["parallelism"] == "replicas1"
+
+
+@pytest.mark.gpu
+def test_bench_launcher_two_ranks_sharing_one_gpu():
+    """`python bench.py --gpus 2` as far as a one-GPU box can take it (SVGF_BENCH_SHARE_DEVICE=1): the launcher spawns two ranks,
+    each creates its own context (both on device 0), the ranks rendezvous over gloo, the timed region is bracketed by the barrier
+    and reduced with MAX (time) / SUM (pixels), and exactly ONE JSON line comes out, from rank 0, with n_gpus = 2 and both
+    ranks' pixels in `value`.  (Real multi-GPU runs use one GPU per rank over RCCL: the branch the one-rank test above takes.)"""
+    import json
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = dict(os.environ, SVGF_BENCH_SHARE_DEVICE="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2", "--no-cpu-baseline",
+                        "--min-warmup-seconds", "0.1", "--latency-calls", "50"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, f"{len(lines)} JSON lines from a 2-rank run"
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 6 and line["scaling"] == "weak"
+    assert line["config"]["parallelism"].startswith("replicas2")
+    # both ranks' pixels over the slower rank's time: two contexts time-slicing one GPU land near (not above ~1.2x) one context's rate
+    px_per_step = 1920 * 1080
+    assert abs(line["value"] * 1e6 * line["ms_per_step"] * 1e-3 - 2 * px_per_step) <= 0.01 * 2 * px_per_step
+    assert "cpu_baseline" not in line and line["latency_ms_sync"] > 0

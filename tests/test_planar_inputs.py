@@ -167,3 +167,43 @@ def test_planar_and_aos_frames_alternate_on_one_context(pkg):
         d.free()
     for f in range(N):
         assert np.array_equal(res[False][f], res[True][f]), f"frame {f}"
+
+
+def test_planar_pointers_survive_a_reset_and_the_fused_first_level_reads_planes(pkg):
+    """(a) svgf_planar_gbuffer() -> svgf_reset() -> producer -> svgf_denoise_planar(): the reset keeps the plane set the
+    pointers name (it used to switch back to set 0, so the producer's planes were not the ones the next frame read), with the
+    reset falling on an odd and on an even frame.  (b) the planar path through the fused temporal + first-level kernel
+    (kernel_variant 6: its loader threads then read normal / position / geomId planes instead of texels) equals the AoS
+    path through the same kernel bit for bit."""
+    import torch
+    W, H = 352, 198
+    rgb = torch.empty((H, W, 3), dtype=torch.float32, device="cuda")
+    gbt = torch.empty((H * W * 52,), dtype=torch.uint8, device="cuda")
+    out = torch.empty((H, W, 3), dtype=torch.float32, device="cuda")
+    for variant in (0, 6):
+        p = pkg.reference_defaults().set(temporal_enable=1, spatial_enable=1, sepcolor=1, addcolor=1, kernel_variant=variant)
+        for reset_at in (1, 2):
+            res = {}
+            for planar in (False, True):
+                d = pkg.Denoiser(W, H, 0)
+                outs = []
+                for f in range(5):
+                    cam = pkg.synth.camera_for_frame(f, True)
+                    if planar:
+                        planes = d.planar_gbuffer()
+                        if f == reset_at:
+                            d.reset()                     # between asking for the planes and filling them
+                        pkg.binding.synth_render_planar(rgb, planes, W, H, cam, f, seed=5)
+                        d.denoise_planar(out, rgb, cam, p)
+                    else:
+                        if f == reset_at:
+                            d.reset()
+                        pkg.binding.synth_render(rgb, gbt, W, H, cam, f, seed=5)
+                        d.denoise(out, rgb, gbt, cam, p)
+                    torch.cuda.synchronize()
+                    outs.append(out.cpu().numpy().copy())
+                res[planar] = (outs, d.read_state(0), d.read_state(1))
+                d.free()
+            for f in range(5):
+                assert np.array_equal(res[False][0][f], res[True][0][f]), f"variant {variant}, reset at {reset_at}: frame {f}"
+            assert np.array_equal(res[False][1], res[True][1]) and np.array_equal(res[False][2], res[True][2])

@@ -31,6 +31,7 @@ def main():
     ap.add_argument("--overlap", type=int, default=0, help="SvgfParams.inputs_ready")
     ap.add_argument("--blur", type=int, default=1, help="SvgfParams.blur_variance")
     ap.add_argument("--reps", type=int, default=20, help="frames of the back-to-back wall-time loop (no per-kernel events)")
+    ap.add_argument("--planar", action="store_true", help="G-buffer handed over as planes (svgf_denoise_planar), static scene")
     a = ap.parse_args()
     import torch
     pkg = ge.load_package()
@@ -46,6 +47,13 @@ def main():
     for v in [int(x) for x in a.variants.split(",")]:
         d = pkg.Denoiser(W, H, 0)
         p = pkg.reference_defaults().set(temporal_enable=1, spatial_enable=1, atrous_nlevel=a.nlevel, kernel_variant=v, inputs_ready=a.overlap, blur_variance=a.blur)
+        if a.planar:      # both plane sets (they alternate with the history) get the static scene's G-buffer; d.denoise then means denoise_planar
+            cam_dict = pkg.synth.camera_for_frame(0, False)
+            for _ in range(2):
+                pkg.binding.synth_render_planar(d_in[0], d.planar_gbuffer(), W, H, cam_dict, 0, seed=5, device=0)
+                d.denoise_planar(out, d_in[0], cam[0], p)
+            torch.cuda.synchronize()
+            d.denoise = lambda o, i, g, c, pp, _d=d: _d.denoise_planar(o, i, c, pp)
         d.profile_enable(a.frames)
         outs = []
         for f in range(a.frames):
