@@ -286,7 +286,10 @@ def main():
             torch.cuda.synchronize(dev)
     torch.cuda.synchronize(dev)
     den.profile_enable(a.steps)
-    tm_all = telemetry.Sampler(local_rank).start()
+    # (SVGF_BENCH_NO_TELEMETRY=1: no sampler thread at all — the A/B that shows whether reading the hwmon nodes disturbs the run)
+    tm_all = telemetry.Sampler(local_rank, period_s=float(os.environ.get("SVGF_BENCH_TELEMETRY_PERIOD", "0.005")))
+    if not os.environ.get("SVGF_BENCH_NO_TELEMETRY"):
+        tm_all.start()
     t_region0 = time.perf_counter()
     dt, pixels = pkg.farm.timed_region(step, a.steps, 0, lambda: torch.cuda.synchronize(dev), dist=dist, device=None if share_device else dev)
     t_region1 = time.perf_counter()

@@ -28,6 +28,7 @@ struct svgf_ctx {
     float *vp[3];          // zero-margined (W+2) x (H+2) copies of cv[k].w: what the step-16/32 levels take their 3x3 variance pre-blur from
     unsigned vp_valid;     // bit k: vp[k] holds the variance of cv[k]
     int use_vplane;        // 0 only for A/B measurements (environment SVGF_NO_VARIANCE_PLANE at svgf_create)
+    void *dump;            // 4 KB of scrap for the fused kernel (TemporalArgs::dump)
     float4 *tp[2];         // cross-level reuse of the geometric terms: four terms per pixel, written by level L for level L+1 (lane kernels
                            // only, svgf_atrous_lane_reuse.hip); allocated when a frame first has two consecutive lane-kernel levels
     int use_reuse;         // 1 only for A/B measurements (environment SVGF_REUSE at svgf_create): measured a loss, profiles/r04_ab_reuse_*.log
@@ -145,6 +146,7 @@ static void free_all(svgf_ctx *c)
     for (int k = 0; k < 3; k++) plane_free(c->cv[k]);
     for (int k = 0; k < 3; k++) if (c->vp[k]) (void)hipFree(c->vp[k]);
     for (int k = 0; k < 2; k++) if (c->tp[k]) (void)hipFree(c->tp[k]);
+    if (c->dump) (void)hipFree(c->dump);
     for (int k = 0; k < 2; k++) {
         plane_free(c->nrm[k]);
         plane_free(c->gid[k]);
@@ -213,6 +215,7 @@ extern "C" int svgf_create(int device, int width, int height, svgf_ctx **out)
     c->fuse_pays = -1;
     bool ok = true;
     for (int k = 0; k < 3 && ok; k++) ok = plane_alloc((void **)&c->cv[k], c->n * sizeof(float4)) == hipSuccess;
+    ok = ok && hipMalloc(&c->dump, 4096) == hipSuccess;
     // (+64 bytes: the step-16/32 lane kernel reads the variance plane in 16-byte pieces that may end 8 bytes behind the last margin)
     for (int k = 0; k < 3 && ok; k++) ok = hipMalloc((void **)&c->vp[k], (size_t)(width + 2) * (height + 2) * sizeof(float) + 64) == hipSuccess;
     for (int k = 0; k < 2 && ok; k++) {
@@ -475,6 +478,7 @@ static int denoise_frame(svgf_ctx *c, void *out_rgb_dev, const void *in_rgb_dev,
         t.W = c->W; t.H = c->H; t.color_alpha_min = p->color_alpha; t.moment_alpha_min = p->moment_alpha;
         t.reproj_sx = p->reproj_scale[0]; t.reproj_sy = p->reproj_scale[1];
         t.pos_prev = c->pos[c->gcur]; t.pos_tol = p->reproj_position_tol;
+        t.dump = c->dump;
         if (cascade && (p->kernel_variant == 0 || p->kernel_variant == 6) && !p->paper_steps && p->spatial_variance_frames <= 0) {
             AtrousArgs probe;
             memset(&probe, 0, sizeof(probe));

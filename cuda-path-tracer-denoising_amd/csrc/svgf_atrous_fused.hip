@@ -32,12 +32,14 @@ double atrous_fused_estimate_us(const AtrousArgs &a, int n_cu)
 hipError_t launch_atrous_fused(const AtrousArgs &a, const TemporalArgs &t, hipStream_t s)
 {
     if (a.step != 2) return hipErrorInvalidValue;
-    return a.dst ? launch_lane_cfg<1, true, 1, 1, true>(a, s, &t) : launch_lane_cfg<1, false, 1, 1, true>(a, s, &t);
+    if (!t.dump) return hipErrorInvalidValue;
+    if (t.gbuf) return a.dst ? launch_lane_cfg<1, true, 1, 1, 1>(a, s, &t) : launch_lane_cfg<1, false, 1, 1, 1>(a, s, &t);
+    return a.dst ? launch_lane_cfg<1, true, 1, 1, 2>(a, s, &t) : launch_lane_cfg<1, false, 1, 1, 2>(a, s, &t);
 }
 
 // step 2 with both y-phases in one workgroup, not fused (reads the accumulated plane like every other level)
 hipError_t launch_atrous_lane_2y(const AtrousArgs &a, hipStream_t s)
 {
     if (a.step != 2) return hipErrorInvalidValue;
-    return a.dst ? launch_lane_cfg<1, true, 1, 1, false>(a, s) : launch_lane_cfg<1, false, 1, 1, false>(a, s);
+    return a.dst ? launch_lane_cfg<1, true, 1, 1, 0>(a, s) : launch_lane_cfg<1, false, 1, 1, 0>(a, s);
 }

@@ -131,8 +131,9 @@ struct LaneNoTemporal {};
 // grows from ~300 to ~600 of 5 300 ticks), one load 1-4 us (its first use waits, in order, for the previous row's stores),
 // against ~3 us the four evaluations are worth, and at 4K the two extra planes (266 MB per level) meet an HBM that is no longer
 // half idle.  Off by default (environment SVGF_REUSE=1 turns it on); kept because it is correct and small.
-template <int LOG2S, bool HASVAR, int LOG2P = LOG2S, int LOG2Y = 0, bool FUSED = false, int REUSE = 0>
-__global__ __launch_bounds__(NT) void k_atrous_lane(AtrousArgs a, LaneGeom gm, std::conditional_t<FUSED, TemporalArgs, LaneNoTemporal> ta)
+// FUSED: 0 no, 1 fused temporal pass reading the AoS G-buffer, 2 fused temporal pass reading the producer's planes
+template <int LOG2S, bool HASVAR, int LOG2P = LOG2S, int LOG2Y = 0, int FUSED = 0, int REUSE = 0>
+__global__ __launch_bounds__(NT) void k_atrous_lane(AtrousArgs a, LaneGeom gm, std::conditional_t<FUSED != 0, TemporalArgs, LaneNoTemporal> ta)
 {
     constexpr bool REUSE_IN = (REUSE & 1) != 0, REUSE_OUT = (REUSE & 2) != 0;
     constexpr int S = 1 << LOG2S;
@@ -140,7 +141,7 @@ __global__ __launch_bounds__(NT) void k_atrous_lane(AtrousArgs a, LaneGeom gm, s
     constexpr int YP = 1 << LOG2Y;               // y-phases held by one workgroup
     constexpr bool CHUNKED = (P < S);
     static_assert(YP == 1 || (YP == 2 && S == 2 && P == S), "two y-phases per workgroup: step 2 only");
-    static_assert(!FUSED || YP == 2, "the fused temporal pass needs the pre-blur rows in the ring");
+    static_assert(FUSED == 0 || YP == 2, "the fused temporal pass needs the pre-blur rows in the ring");
     constexpr int WPP = NWC / (P * YP);          // waves per x-phase (and y-phase)
     constexpr int TXW = TXO / YP;                // output pixel columns per workgroup
     constexpr int M = LOUT * WPP + 4;            // lattice columns per phase in the ring (2 halo either side)
@@ -448,16 +449,31 @@ __global__ __launch_bounds__(NT) void k_atrous_lane(AtrousArgs a, LaneGeom gm, s
     // per SIMD leave: the colour is fetched in stage C rather than in A (3 registers), ring record and pixel index are re-derived.
     // ====================================================================================================================
     struct TA_ { float nx, ny, nz, px, py, pz; int gid, N; };                         // stage A: primary data
-    struct TB_ { int g4[4]; float nq[12]; };                                            // stage B: geomId + normal of the bilinear quad (0,0) (1,0) (0,1) (1,1)
-    // stage C request: d[6k .. 6k+5] = {colour, moments, length} of quad tap k (mode 1), or d[3j .. 3j+2] = normal and d[15 + j] =
-    // geomId of the fallback's extra tap j (mode 2); rgb = the pixel's 1-spp colour
-    struct TC_ { float d[24]; float cr, cg, cb; SvgfReproj rp; int mode, m9; };
+    // Carried values keep the SHAPE of the loads that fetch them (vector types, one per load instruction): a scalar array filled
+    // from a wide load makes the register allocator load into a scratch tuple and copy — behind an s_waitcnt for a load it has
+    // just issued (r04_exp_fused_v7: two exposed round trips per sub-step in stage B alone).  The pointer types say "4-byte
+    // aligned": the plane elements are.
+    typedef float v3f __attribute__((ext_vector_type(3)));
+    typedef int v2i __attribute__((ext_vector_type(2)));
+    typedef v2f __attribute__((aligned(4))) v2f_u;
+    typedef v3f __attribute__((aligned(4))) v3f_u;
+    typedef v4f __attribute__((aligned(4))) v4f_u;
+    typedef v2i __attribute__((aligned(4))) v2i_u;
+    // stage B: the bilinear quad, one row piece per window row yy = 0, 1: geomId of taps (0, yy), (1, yy); their normals as 4 + 2 floats
+    struct TB_ { v2i g[2]; v4f n4[2]; v2f n2[2]; };
+    // Stage C1's request, ONE static shape of nine loads whatever the pixel needs (a load count that depended on the pixel would
+    // make every later s_waitcnt conservative, see the pipeline below): five 12-byte, two 16-byte and two 8-byte pieces whose
+    // ADDRESSES are per lane.  mode 1 (bilinear): colour, moments, history length of the quad's four taps.  mode 2 (3x3 fallback):
+    // normal and geomId of the other five window taps 0, 1, 2, 3, 6.  mode 0: whatever lies at clamped addresses, never read.
+    // (as vectors: h3[k] = colour of quad tap k | normal of extra tap k (k = 4: extra tap 6 only); h4[yy] = moments of quad taps
+    // (0, yy), (1, yy) | h4[0].xyz = geomIds of window row -1; h2[yy] = history lengths of those two taps | h2[yy].x = geomId of
+    // window tap 3 (yy = 0), 6 (yy = 1))
+    struct TC_ { v3f h3[5]; v4f h4[2]; v2f h2[2]; v3f rgb; SvgfReproj rp; int mode, m9; };
     // Element index (+ 2) of the 3x3 window's row yy (-1, 0, 1), first column (fx - 1).  Rows are clamped into the image, the
     // first column into [-2, W - 1]: a window with any tap on screen has fx in [-1, W] and is read where it lies — its off-screen
     // taps fall at most two elements outside a row, i.e. inside the planes' padding at the two ends of a plane (svgf_api.hip:
     // kPlanePad) — and every tap's validity comes from svgf_tap_index() on the float coordinates, never from the address.
-    // The + 2 makes it a non-negative offset from (plane - 2 elements): with an unsigned 32-bit offset the loads take the
-    // scalar-base + vector-offset form (one address register instead of a 64-bit pair per load).
+    // The + 2 makes it a non-negative offset from (plane - 2 elements).
     [[maybe_unused]] auto t_window_row = [&](float fx, float fy, int yy) -> unsigned {
         const float fxc = fminf(fmaxf(fx, -1.0f), (float)W);              // NaN -> -1
         const float fyc = fminf(fmaxf(fy + (float)yy, 0.0f), (float)(H - 1));
@@ -466,24 +482,25 @@ __global__ __launch_bounds__(NT) void k_atrous_lane(AtrousArgs a, LaneGeom gm, s
     [[maybe_unused]] auto t_at = [](const void *plane, unsigned elem_plus_2, unsigned elem_bytes) -> const char * {
         return reinterpret_cast<const char *>(plane) - 2 * (long)elem_bytes + elem_plus_2 * elem_bytes;
     };
+    constexpr int kLdsDump = RING_BYTES + 32;          // 48 bytes nobody reads: the ring record of a thread's idle pixel slot
     // pixel (lattice row br, y-phase yp, staged column xi) -> ring record, pixel index, flags (1: inside the image, 2: owned)
     [[maybe_unused]] auto t_describe = [&](int br, int yp, int xi, bool active, int &lds_off, unsigned &p, int &flags) {
         const int y = phase + yp + (br << LOG2S);
         const int xs = xs_of(xi);
         const bool ok = active && (br >= 0) && (y < H) && (xs >= 0) && (xs < W);
         const bool owned = ok && (br >= b0) && (br < b1) && (xi >= 2 * S) && (xi < 2 * S + TXW);
-        lds_off = active ? (slot_mod(br) * YP + yp) * ROWB + rec_of(xi) : -1;      // an idle slot must not store anything
+        lds_off = active ? (slot_mod(br) * YP + yp) * ROWB + rec_of(xi) : kLdsDump;
         p = (unsigned)min(max(y, 0), H - 1) * (unsigned)W + (unsigned)min(max(xs, 0), W - 1);
         flags = (ok ? 1 : 0) | (owned ? 2 : 0);
     };
-    [[maybe_unused]] auto t_stage_a = [&](TA_ &t, unsigned p) {
-        if constexpr (FUSED) {
+    [[maybe_unused]] auto t_stage_a = [&](TA_ &t, unsigned p) __attribute__((always_inline)) {
+        if constexpr (FUSED != 0) {
             // (unsigned 32-bit byte offsets: scalar base + vector offset addressing; W * H * 52 < 2^32 is checked by the launcher)
-            if (ta.gbuf) {
+            if constexpr (FUSED == 1) {         // the boundary's AoS texels
                 const float *g = reinterpret_cast<const float *>(reinterpret_cast<const char *>(ta.gbuf) + p * 52u);
                 t.nx = g[0]; t.ny = g[1]; t.nz = g[2]; t.px = g[3]; t.py = g[4]; t.pz = g[5];
                 t.gid = __float_as_int(g[12]);
-            } else {
+            } else {                            // planes written in place by the producer (svgf_planar_gbuffer)
                 const float *n = reinterpret_cast<const float *>(reinterpret_cast<const char *>(ta.nrm_cur) + p * 12u);
                 const float *q = reinterpret_cast<const float *>(reinterpret_cast<const char *>(ta.pos_cur) + p * 12u);
                 t.nx = n[0]; t.ny = n[1]; t.nz = n[2]; t.px = q[0]; t.py = q[1]; t.pz = q[2];
@@ -494,86 +511,69 @@ __global__ __launch_bounds__(NT) void k_atrous_lane(AtrousArgs a, LaneGeom gm, s
     };
     // history lookup wanted (:197): the pixel is inside the image, has a history and hit something
     [[maybe_unused]] auto t_wants_history = [&](const TA_ &a_, int flags) { return (flags & 1) && a_.N > 0 && a_.gid != -1; };
-    [[maybe_unused]] auto t_stage_b = [&](const TA_ &a_, int flags, TB_ &b_, SvgfReproj &rp_out) {
-        if constexpr (FUSED) {
-            if (t_wants_history(a_, flags)) {
-                const SvgfReproj rp = svgf_reproject(ta, a_.px, a_.py, a_.pz);
-                rp_out = rp;
+    // (unconditional: a pixel that wants no history reprojects whatever its position is — NaN included — and reads clamped
+    // addresses; nothing of it is used)
+    [[maybe_unused]] auto t_stage_b = [&](const TA_ &a_, TB_ &b_, SvgfReproj &rp_out) __attribute__((always_inline)) {
+        if constexpr (FUSED != 0) {
+            const SvgfReproj rp = svgf_reproject(ta, a_.px, a_.py, a_.pz);
+            rp_out = rp;
 #pragma unroll
-                for (int yy = 0; yy <= 1; yy++) {                         // the bilinear quad: taps (0, yy), (1, yy), one row piece each
-                    const unsigned e = t_window_row(rp.fx, rp.fy, yy) + 1u;
-                    const int *gp = reinterpret_cast<const int *>(t_at(ta.gid_prev, e, 4u));
-                    const float *np = reinterpret_cast<const float *>(t_at(ta.nrm_prev, e, 12u));
-                    b_.g4[2 * yy] = gp[0]; b_.g4[2 * yy + 1] = gp[1];
-#pragma unroll
-                    for (int j = 0; j < 6; j++) b_.nq[6 * yy + j] = np[j];
-                }
+            for (int yy = 0; yy <= 1; yy++) {                             // the bilinear quad: taps (0, yy), (1, yy), one row piece each
+                const unsigned e = t_window_row(rp.fx, rp.fy, yy) + 1u;
+                const char *np = t_at(ta.nrm_prev, e, 12u);
+                b_.g[yy] = *reinterpret_cast<const v2i_u *>(t_at(ta.gid_prev, e, 4u));
+                b_.n4[yy] = *reinterpret_cast<const v4f_u *>(np);
+                b_.n2[yy] = *reinterpret_cast<const v2f_u *>(np + 16);
             }
         }
     };
-    [[maybe_unused]] auto t_stage_c1 = [&](const TA_ &a_, const TB_ &b_, const SvgfReproj &rp_in, int flags, unsigned p, TC_ &c_) {
-        if constexpr (FUSED) {
-            const float *c = reinterpret_cast<const float *>(reinterpret_cast<const char *>(ta.in_rgb) + p * 12u);
-            c_.cr = c[0]; c_.cg = c[1]; c_.cb = c[2];
-            c_.mode = 0; c_.m9 = 0;
-            c_.rp.fx = 0.0f; c_.rp.fy = 0.0f; c_.rp.fracx = 0.0f; c_.rp.fracy = 0.0f;
-            if (t_wants_history(a_, flags)) {
-                const SvgfReproj rp = rp_in;
-                c_.rp = rp;
-                int m9 = 0;                                               // taps on screen (:173-176), bit (yy + 1) * 3 + xx + 1
+    [[maybe_unused]] auto t_stage_c1 = [&](const TA_ &a_, const TB_ &b_, const SvgfReproj &rp, int flags, unsigned p, TC_ &c_) __attribute__((always_inline)) {
+        if constexpr (FUSED != 0) {
+            c_.rgb = *reinterpret_cast<const v3f_u *>(reinterpret_cast<const char *>(ta.in_rgb) + p * 12u);
+            c_.rp = rp;
+            const bool wants = t_wants_history(a_, flags);
+            int m9 = 0;                                                   // taps on screen (:173-176), bit (yy + 1) * 3 + xx + 1
 #pragma unroll
-                for (int k = 0; k < 9; k++)
-                    m9 |= (svgf_tap_index(ta, rp.fx + (float)(k % 3 - 1), rp.fy + (float)(k / 3 - 1)) >= 0) ? (1 << k) : 0;
-                // the bilinear quad: window taps 4, 5, 7, 8; its geomIds and normals are here: consistency test (:177-180)
-                constexpr int quad[4] = { 4, 5, 7, 8 };
-                bool all = (rp.fx >= 0.0f && rp.fy >= 0.0f && rp.fx < (float)W && rp.fy < (float)H);
+            for (int k = 0; k < 9; k++)
+                m9 |= (svgf_tap_index(ta, rp.fx + (float)(k % 3 - 1), rp.fy + (float)(k / 3 - 1)) >= 0) ? (1 << k) : 0;
+            m9 = wants ? m9 : 0;
+            // the bilinear quad: window taps 4, 5, 7, 8; its geomIds and normals are here: consistency test (:177-180)
+            constexpr int quad[4] = { 4, 5, 7, 8 };
+            bool all = wants & (rp.fx >= 0.0f) & (rp.fy >= 0.0f) & (rp.fx < (float)W) & (rp.fy < (float)H);
 #pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    const bool ok = ((m9 >> quad[k]) & 1) & svgf_tap_consistent(b_.g4[k], b_.nq[3 * k], b_.nq[3 * k + 1], b_.nq[3 * k + 2], a_.gid, a_.nx, a_.ny, a_.nz);
-                    if (!ok) m9 &= ~(1 << quad[k]);
-                    all = all && ok;
-                }
-                c_.m9 = m9;
-                c_.mode = all ? 1 : 2;
-                if (all) {                                                // bilinear: the quad's history, two row pieces
+            for (int k = 0; k < 4; k++) {
+                const int yy = k >> 1;
+                const bool right = (k & 1) != 0;      // tap (1, yy): the second geomId, the floats 3, 4, 5 of the row piece
+                const bool ok = ((m9 >> quad[k]) & 1) & svgf_tap_consistent(right ? b_.g[yy].y : b_.g[yy].x, right ? b_.n4[yy].w : b_.n4[yy].x,
+                                                                            right ? b_.n2[yy].x : b_.n4[yy].y, right ? b_.n2[yy].y : b_.n4[yy].z, a_.gid, a_.nx, a_.ny, a_.nz);
+                m9 = ok ? m9 : (m9 & ~(1 << quad[k]));
+                all = all & ok;
+            }
+            c_.m9 = m9;
+            c_.mode = wants ? (all ? 1 : 2) : 0;
+            const unsigned em = t_window_row(rp.fx, rp.fy, -1), e0 = t_window_row(rp.fx, rp.fy, 0), e1 = t_window_row(rp.fx, rp.fy, 1);
+            // five 12-byte pieces: the quad's history colours, or the normals of window taps 0, 1, 2, 3, 6
 #pragma unroll
-                    for (int yy = 0; yy <= 1; yy++) {
-                        const unsigned e = t_window_row(rp.fx, rp.fy, yy) + 1u;
-                        const float *ch = reinterpret_cast<const float *>(t_at(ta.cv_hist, e, 16u));
-                        const float *m = reinterpret_cast<const float *>(t_at(ta.mom_hist, e, 8u));
-                        const int *l = reinterpret_cast<const int *>(t_at(ta.hlen, e, 4u));
+            for (int k = 0; k < 5; k++) {
+                const char *hist = t_at(ta.cv_hist, (k < 2 ? e0 : e1) + 1u + (unsigned)(k & 1), 16u);
+                const char *nrmp = t_at(ta.nrm_prev, k < 3 ? em + (unsigned)k : (k == 3 ? e0 : e1), 12u);
+                c_.h3[k] = *reinterpret_cast<const v3f_u *>((all && k < 4) ? hist : nrmp);
+            }
+            // two 16-byte pieces: the quad's history moments (two taps a row), or the geomIds of window row -1
 #pragma unroll
-                        for (int xx = 0; xx <= 1; xx++) {
-                            const int k = 2 * yy + xx;
-                            c_.d[6 * k] = ch[4 * xx]; c_.d[6 * k + 1] = ch[4 * xx + 1]; c_.d[6 * k + 2] = ch[4 * xx + 2];
-                            c_.d[6 * k + 3] = m[2 * xx]; c_.d[6 * k + 4] = m[2 * xx + 1];
-                            c_.d[6 * k + 5] = __int_as_float(l[xx]);
-                        }
-                    }
-                } else if (m9 & 0x4f) {                                   // fallback: geomId + normal of the on-screen taps 0, 1, 2, 3, 6
-                    {
-                        const unsigned e = t_window_row(rp.fx, rp.fy, -1);
-                        const float *np = reinterpret_cast<const float *>(t_at(ta.nrm_prev, e, 12u));
-                        const int *gp = reinterpret_cast<const int *>(t_at(ta.gid_prev, e, 4u));
+            for (int yy = 0; yy <= 1; yy++) {
+                c_.h4[yy] = *reinterpret_cast<const v4f_u *>(all ? t_at(ta.mom_hist, (yy ? e1 : e0) + 1u, 8u) : t_at(ta.gid_prev, em, 4u));
+            }
+            // two 8-byte pieces: the quad's history lengths, or the geomIds of window taps 3 and 6 (first element)
 #pragma unroll
-                        for (int k = 0; k < 9; k++) c_.d[k] = np[k];
-#pragma unroll
-                        for (int k = 0; k < 3; k++) c_.d[15 + k] = __int_as_float(gp[k]);
-                    }
-#pragma unroll
-                    for (int yy = 0; yy <= 1; yy++) {
-                        const unsigned e = t_window_row(rp.fx, rp.fy, yy);
-                        const float *np = reinterpret_cast<const float *>(t_at(ta.nrm_prev, e, 12u));
-                        c_.d[9 + 3 * yy] = np[0]; c_.d[10 + 3 * yy] = np[1]; c_.d[11 + 3 * yy] = np[2];
-                        c_.d[18 + yy] = __int_as_float(*reinterpret_cast<const int *>(t_at(ta.gid_prev, e, 4u)));
-                    }
-                }
+            for (int yy = 0; yy <= 1; yy++) {
+                c_.h2[yy] = *reinterpret_cast<const v2f_u *>(all ? t_at(ta.hlen, (yy ? e1 : e0) + 1u, 4u) : t_at(ta.gid_prev, yy ? e1 : e0, 4u));
             }
         }
     };
-    [[maybe_unused]] auto t_stage_c2 = [&](const TA_ &a_, const TC_ &c_, int flags, unsigned p, int lds_off) {
-        if constexpr (FUSED) {
-            const float lum = svgf_lum_strict(c_.cr, c_.cg, c_.cb);
+    [[maybe_unused]] auto t_stage_c2 = [&](const TA_ &a_, const TC_ &c_, int flags, unsigned p, int lds_off) __attribute__((always_inline)) {
+        if constexpr (FUSED != 0) {
+            const float lum = svgf_lum_strict(c_.rgb.x, c_.rgb.y, c_.rgb.z);
             SvgfHistSum hs = { 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f };
             bool valid = false;
             if (c_.mode == 1) {                                       // bilinear (:234-259)
@@ -582,7 +582,10 @@ __global__ __launch_bounds__(NT) void k_atrous_lane(AtrousArgs a, LaneGeom gm, s
                 float sumw = 0.0f;
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
-                    svgf_hist_add_weighted(hs, w[k], c_.d[6 * k], c_.d[6 * k + 1], c_.d[6 * k + 2], c_.d[6 * k + 3], c_.d[6 * k + 4], __float_as_int(c_.d[6 * k + 5]));
+                    const int yy = k >> 1;
+                    const bool right = (k & 1) != 0;
+                    svgf_hist_add_weighted(hs, w[k], c_.h3[k].x, c_.h3[k].y, c_.h3[k].z, right ? c_.h4[yy].z : c_.h4[yy].x, right ? c_.h4[yy].w : c_.h4[yy].y,
+                                           __float_as_int(right ? c_.h2[yy].y : c_.h2[yy].x));
                     sumw += w[k];
                 }
                 if ((double)sumw >= 0.01) svgf_hist_div(hs, sumw);
@@ -590,12 +593,14 @@ __global__ __launch_bounds__(NT) void k_atrous_lane(AtrousArgs a, LaneGeom gm, s
             } else if (c_.mode == 2) {                                // 3x3 box around floor (:262-286)
                 int m9 = c_.m9;
                 constexpr int extra[5] = { 0, 1, 2, 3, 6 };
-                if (m9 & 0x4f) {                                      // (the condition stage C1 requested their data under)
+                const int ge[5] = { __float_as_int(c_.h4[0].x), __float_as_int(c_.h4[0].y), __float_as_int(c_.h4[0].z), __float_as_int(c_.h2[0].x), __float_as_int(c_.h2[1].x) };
 #pragma unroll
-                    for (int j = 0; j < 5; j++)
-                        if (!svgf_tap_consistent(__float_as_int(c_.d[15 + j]), c_.d[3 * j], c_.d[3 * j + 1], c_.d[3 * j + 2], a_.gid, a_.nx, a_.ny, a_.nz)) m9 &= ~(1 << extra[j]);
-                }
+                for (int j = 0; j < 5; j++)
+                    if (!svgf_tap_consistent(ge[j], c_.h3[j].x, c_.h3[j].y, c_.h3[j].z, a_.gid, a_.nx, a_.ny, a_.nz)) m9 &= ~(1 << extra[j]);
                 if (m9) {                                             // a consistent tap exists: the window's history, one row piece at a time
+                    // (The one place of the pipeline that waits for loads it has just issued: rare in steady state — a pixel next to
+                    // an edge whose reprojection still finds part of its surface.  The branch ends with nothing of it in flight, so
+                    // the s_waitcnt bookkeeping of the main path is the same whether it was taken or not.)
                     float cnt = 0.0f;
 #pragma unroll 1
                     for (int yy = -1; yy <= 1; yy++) {
@@ -622,45 +627,55 @@ __global__ __launch_bounds__(NT) void k_atrous_lane(AtrousArgs a, LaneGeom gm, s
                     valid = true;
                 }
             }
-            const SvgfTemporalOut o = svgf_temporal_blend(ta, c_.cr, c_.cg, c_.cb, lum, a_.N, valid, hs);
-            // ring record, as rows_store() writes it
+            const SvgfTemporalOut o = svgf_temporal_blend(ta, c_.rgb.x, c_.rgb.y, c_.rgb.z, lum, a_.N, valid, hs);
+            // ring record, as rows_store() writes it (an idle slot's goes to kLdsDump)
             const bool ok = (flags & 1) != 0;
             const float inf = __builtin_huge_valf();
             const float mag = fabsf(a_.nx) + fabsf(a_.ny) + fabsf(a_.nz) + fabsf(a_.px) + fabsf(a_.py) + fabsf(a_.pz);
-            if (!(mag < inf)) *nan_seen = 1;
+            if (ok && !(mag < inf)) *nan_seen = 1;
             char *d = smem + lds_off;
             *reinterpret_cast<float4 *>(d) = make_float4(a_.nx, a_.px, a_.ny, a_.py);
             *reinterpret_cast<float4 *>(d + 16) = make_float4(a_.nz, a_.pz, ok ? lum_f64(o.cv.x, o.cv.y, o.cv.z) : inf, 0.0f);
             *reinterpret_cast<float4 *>(d + 32) = ok ? o.cv : make_float4(0.f, 0.f, 0.f, 0.f);
-            if (flags & 2) {                                          // owned: the planes the rest of the frame (and the next) reads
-                *reinterpret_cast<int *>(reinterpret_cast<char *>(ta.hlen_upd) + p * 4u) = o.hlen;
-                *reinterpret_cast<float2 *>(reinterpret_cast<char *>(ta.mom_acc) + p * 8u) = o.mom;
-                if (ta.cv_acc) *reinterpret_cast<float4 *>(reinterpret_cast<char *>(ta.cv_acc) + p * 16u) = o.cv;   // only when something besides this level reads the accumulated plane
-                if (ta.gbuf) {
-                    float *n = reinterpret_cast<float *>(reinterpret_cast<char *>(ta.nrm_cur) + p * 12u);
-                    float *q = reinterpret_cast<float *>(reinterpret_cast<char *>(ta.pos_cur) + p * 12u);
-                    n[0] = a_.nx; n[1] = a_.ny; n[2] = a_.nz; q[0] = a_.px; q[1] = a_.py; q[2] = a_.pz;
-                    *reinterpret_cast<int *>(reinterpret_cast<char *>(ta.gid_cur) + p * 4u) = a_.gid;
-                }
+            // The planes the rest of the frame (and the next) reads: written for the pixels this workgroup OWNS.  Every thread
+            // issues every store — a pixel that is not owned stores into a scrap buffer (ta.dump) — so that the NUMBER of
+            // vector-memory operations of a sub-step does not depend on the pixel (see the pipeline below).
+            const bool owned = (flags & 2) != 0;
+            char *scrap = reinterpret_cast<char *>(ta.dump) + (tid & 255) * 16;
+            *reinterpret_cast<int *>(owned ? reinterpret_cast<char *>(ta.hlen_upd) + p * 4u : scrap) = o.hlen;
+            *reinterpret_cast<float2 *>(owned ? reinterpret_cast<char *>(ta.mom_acc) + p * 8u : scrap) = o.mom;
+            // (the accumulated plane itself: only when something besides this level reads it)
+            *reinterpret_cast<float4 *>((owned && ta.cv_acc) ? reinterpret_cast<char *>(ta.cv_acc) + p * 16u : scrap) = o.cv;
+            if constexpr (FUSED == 1) {
+                float *n = reinterpret_cast<float *>(owned ? reinterpret_cast<char *>(ta.nrm_cur) + p * 12u : scrap);
+                float *q = reinterpret_cast<float *>(owned ? reinterpret_cast<char *>(ta.pos_cur) + p * 12u : scrap);
+                n[0] = a_.nx; n[1] = a_.ny; n[2] = a_.nz; q[0] = a_.px; q[1] = a_.py; q[2] = a_.pz;
+                *reinterpret_cast<int *>(owned ? reinterpret_cast<char *>(ta.gid_cur) + p * 4u : scrap) = a_.gid;
             }
         }
     };
 
-    if constexpr (FUSED) {
+    if constexpr (FUSED != 0) {
         // One software pipeline for the prologue and the loop, ONE pixel per thread and sub-step.  Pixel q of a thread:
         //   q = 0 .. 3     the ten prologue rows b0-2 .. b0+2 (both y-phases), dealt over all 768 threads, four pixels each;
         //   q >= 4         lattice row b0+3 + (q-4)/2, y-phase (q-4) & 1, at the staged column a LOADER thread owns.
         // Sub-step u runs stage C2 of pixel u-4, C1 of pixel u-3, B of pixel u-2 and A of pixel u: every stage's loads have at
-        // least one sub-step to land and no stage waits for a load it has just issued (the 3x3 fallback's history excepted).
-        // After sub-step 7 the prologue rows are in the ring (first barrier; the compute threads leave for their warm-up rows);
-        // sub-steps 8+2i, 9+2i are iteration i of the loop: they commit the two y-phases of lattice row bo+3 while the compute
-        // waves work on output row bo = b0+i.  One pixel per stage keeps the carried state at ~80 registers (two pixels per
-        // stage did not fit the 168 that three waves per SIMD leave: every variant spilled, and a spill reload inside the loop
-        // waits for every load in flight).
+        // least one sub-step to land.  After sub-step 7 the prologue rows are in the ring (first barrier; the compute threads
+        // leave for their warm-up rows); sub-steps 8+2i, 9+2i are iteration i of the loop: they commit the two y-phases of
+        // lattice row bo+3 while the compute waves work on output row bo = b0+i.
+        // What makes or breaks it is s_waitcnt: vmcnt counts loads AND stores, in order, and the compiler can only wait for
+        // "all but the N youngest" when it knows N.  A vector-memory operation under a condition — a store for owned pixels
+        // only, history loads for pixels that have a history — makes N unknown, every wait becomes vmcnt(0), and vmcnt(0)
+        // behind freshly issued stores waits for their acknowledgements: 3-5 thousand ticks, twice a sub-step
+        // (profiles/r04_exp_fused_v5_timeline.log, r04_exp_fused_v6_timeline.log: 213-219 us per 1080p frame).  So every
+        // sub-step of the loop issues the SAME operations whatever its pixel is: loads from clamped addresses, stores into a
+        // scrap buffer, one request shape for stage C1; the buffers of stage A alternate statically (loop unrolled by two:
+        // rotating them by assignment copies registers whose loads are in flight); one pixel per stage keeps the carried
+        // state at ~85 registers (two pixels per stage did not fit the 168 that three waves per SIMD leave).
         const int lt = tid - NC;                        // loader thread index (loader threads only)
         const int lxi = min(max(lt, 0), RW - 1);        // the staged column a loader thread owns in the loop
         const bool lactive = is_loader && lt < RW;
-        auto describe_px = [&](int q, int &lo, unsigned &p, int &fl) {
+        auto describe_px = [&](int q, int &lo, unsigned &p, int &fl) __attribute__((always_inline)) {
             int br, yp, xi;
             bool active;
             if (q < 4) {
@@ -676,51 +691,66 @@ __global__ __launch_bounds__(NT) void k_atrous_lane(AtrousArgs a, LaneGeom gm, s
             }
             t_describe(br, yp, xi, active, lo, p, fl);
         };
-        TA_ a0, a1;                                     // stage A of pixels u-1, u-2
+        TA_ a_even, a_odd;                              // stage A of the pixels with even / odd index
         TA_ ab; TB_ bb; SvgfReproj rb;                  // the pixel between stages B and C1
         TA_ ac; TC_ cc;                                 // the pixel between stages C1 and C2
-        rb.fx = rb.fy = rb.fracx = rb.fracy = 0.0f;
         if (is_loader) __builtin_amdgcn_s_setprio(SVGF_LANE_LOADER_PRIO);
         const int n_sub = 8 + 2 * (b1 - b0);
-#pragma unroll 1
-        for (int u = 0; u < n_sub; u++) {
-            if (u >= 8 && !(u & 1)) stamp(0);
-            if (u >= 4) {                               // C2: blend, ring record + planes
+        // abuf: holds pixel u-2 on entry (stage B reads it), pixel u on exit.  PRO: the prologue's sub-steps 0 .. 7, where the
+        // pipeline fills and all 768 threads take part; else the loop's, loader threads only, every stage every time.
+        auto substep = [&](int u, TA_ &abuf, auto pro_tag) __attribute__((always_inline)) {
+            constexpr bool PRO = decltype(pro_tag)::value;
+            if (!PRO && !(u & 1)) stamp(0);
+            if (!PRO || u >= 4) {                               // C2: blend, ring record + planes
                 int lo, fl; unsigned p;
                 describe_px(u - 4, lo, p, fl);
-                if (lo >= 0) t_stage_c2(ac, cc, fl, p, lo);
+                t_stage_c2(ac, cc, fl, p, lo);
             }
-            if (u >= 8 && !(u & 1)) stamp(1);
-            if (u >= 3 && (u - 3 < 4 || is_loader)) {   // C1: consistency, history request
+            if (!PRO && !(u & 1)) stamp(1);
+            if (!PRO || (u >= 3 && (u - 3 < 4 || is_loader))) { // C1: consistency, history request
                 int lo, fl; unsigned p;
                 describe_px(u - 3, lo, p, fl);
                 ac = ab;
                 t_stage_c1(ac, bb, rb, fl, p, cc);
             }
-            if (u >= 8 && !(u & 1)) stamp(2);
-            if (u >= 2 && (u - 2 < 4 || is_loader)) {   // B: reprojection, consistency data of the bilinear quad
-                int lo, fl; unsigned p;
-                describe_px(u - 2, lo, p, fl);
-                ab = a1;
-                t_stage_b(ab, fl, bb, rb);
+            if (!PRO && !(u & 1)) stamp(2);
+            if (!PRO || (u >= 2 && (u - 2 < 4 || is_loader))) { // B: reprojection, consistency data of the bilinear quad
+                ab = abuf;
+                t_stage_b(ab, bb, rb);
             }
-            if (u >= 8 && !(u & 1)) stamp(3);
-            a1 = a0;
-            if (u < 4 || is_loader) {                   // A: primary loads
+            if (!PRO && !(u & 1)) stamp(3);
+            if (!PRO || u < 4 || is_loader) {                   // A: primary loads
                 int lo, fl; unsigned p;
                 describe_px(u, lo, p, fl);
-                t_stage_a(a0, p);
+                t_stage_a(abuf, p);
             }
-            if (u >= 8 && !(u & 1)) stamp(4);
-            if (u >= 7 && (u & 1)) {
-                if (u >= 9) stamp(5);
-                __syncthreads();
-                if (u == 7) stamp_at(1);
-                if (u >= 9) { stamp(6); ring_advance(); dbg_it++; }
-                if (!is_loader) break;
-            }
+            if (!PRO && !(u & 1)) stamp(4);
+        };
+#pragma unroll 1
+        for (int u = 0; u < 8; u += 2) {
+            substep(u, a_even, std::true_type{});
+            substep(u + 1, a_odd, std::true_type{});
         }
-        if (is_loader) return;
+        __syncthreads();
+        stamp_at(1);
+        if (is_loader) {
+            // The loop's first iteration is peeled: the s_waitcnt pass merges the states of a loop header's predecessors, and a wait
+            // for "all but the N youngest" survives the merge only if N is the same on both — with the prologue's branchy state
+            // (or an empty one) on one side, the first waits of every iteration came out as vmcnt(0): one drained pipeline per
+            // iteration.  Entered from a copy of its own body, the header sees the same sequence on both edges.
+            auto iteration = [&](int u) __attribute__((always_inline)) {
+                substep(u, a_even, std::false_type{});
+                substep(u + 1, a_odd, std::false_type{});
+                stamp(5);
+                __syncthreads();
+                stamp(6);
+                ring_advance(); dbg_it++;
+            };
+            iteration(8);
+#pragma unroll 1
+            for (int u = 10; u < n_sub; u += 2) iteration(u);
+            return;
+        }
     } else {
 #if SVGF_LANE_SPLIT_PROLOGUE
     // ---------------- prologue in two steps.  All 256 workgroups start at once and each wants five ring rows, a burst that
@@ -984,7 +1014,7 @@ __global__ __launch_bounds__(NT) void k_atrous_lane(AtrousArgs a, LaneGeom gm, s
 #pragma unroll 1
     for (int bw = b0 - 2; bw < b0; bw++) {
 #if SVGF_LANE_SPLIT_PROLOGUE
-        if constexpr (!FUSED) { if (bw == b0 - 1) __syncthreads(); }     // rows b0+1, b0+2 are published by the loader threads (see the prologue)
+        if constexpr (FUSED == 0) { if (bw == b0 - 1) __syncthreads(); }     // rows b0+1, b0+2 are published by the loader threads (see the prologue)
 #endif
         const char *rowc = colbase + slot_of(bw) * RSTR + 2 * PXB;
         const v4f A = *reinterpret_cast<const v4f *>(rowc);
@@ -1304,11 +1334,11 @@ inline long lane_segment_search(int n_strips, int S, int nb_max, int n_cu, int *
     return best_cost;
 }
 
-template <int LOG2S, bool HASVAR, int LOG2P = LOG2S, int LOG2Y = 0, bool FUSED = false, int REUSE = 0>
+template <int LOG2S, bool HASVAR, int LOG2P = LOG2S, int LOG2Y = 0, int FUSED = 0, int REUSE = 0>
 hipError_t launch_lane_cfg(const AtrousArgs &a, hipStream_t s, const TemporalArgs *ta = nullptr)
 {
     constexpr int S = 1 << LOG2S, P = 1 << LOG2P, YP = 1 << LOG2Y, M = LOUT * (NWC / (P * YP)) + 4, MP = (P == 4) ? M + 2 : ((M * 12 % 64 == 0) ? M + 1 : M), BM = (BW + S - 1) / S;
-    constexpr size_t kLds = (size_t)R * YP * P * MP * PXB + (size_t)2 * (YP > 1 ? 0 : (P < S ? P * M : 2 * S * BM)) * 4 + 16;
+    constexpr size_t kLds = (size_t)R * YP * P * MP * PXB + (size_t)2 * (YP > 1 ? 0 : (P < S ? P * M : 2 * S * BM)) * 4 + 16 + (FUSED != 0 ? 80 : 0);
     const size_t lds = kLds;
     static_assert(kLds <= 160 * 1024, "LDS budget");
     static SvgfLaunchCache cache;
@@ -1339,8 +1369,8 @@ hipError_t launch_lane_cfg(const AtrousArgs &a, hipStream_t s, const TemporalArg
         gm.dbg = dbg_buf; gm.dbg_block = atoi(dbg_env);
     }
 #endif
-    if constexpr (FUSED) hipLaunchKernelGGL((k_atrous_lane<LOG2S, HASVAR, LOG2P, LOG2Y, true, REUSE>), dim3(nblocks), dim3(NT), lds, s, a, gm, *ta);
-    else hipLaunchKernelGGL((k_atrous_lane<LOG2S, HASVAR, LOG2P, LOG2Y, false, REUSE>), dim3(nblocks), dim3(NT), lds, s, a, gm, LaneNoTemporal{});
+    if constexpr (FUSED != 0) hipLaunchKernelGGL((k_atrous_lane<LOG2S, HASVAR, LOG2P, LOG2Y, FUSED, REUSE>), dim3(nblocks), dim3(NT), lds, s, a, gm, *ta);
+    else hipLaunchKernelGGL((k_atrous_lane<LOG2S, HASVAR, LOG2P, LOG2Y, 0, REUSE>), dim3(nblocks), dim3(NT), lds, s, a, gm, LaneNoTemporal{});
 #ifdef SVGF_LANE_TIMELINE
     if (dbg_env) {
         static int skip = getenv("SVGF_LANE_DBG_SKIP") ? atoi(getenv("SVGF_LANE_DBG_SKIP")) : 0, prints = 0;
@@ -1359,7 +1389,7 @@ hipError_t launch_lane_cfg(const AtrousArgs &a, hipStream_t s, const TemporalArg
                             h[(w * 16) * 8 + 0] - h[(w * 16) * 8 + 7]);
                 for (int it = 0; it < 8 && h[(w * 16 + it) * 8]; it++) {
                     unsigned long long *t = &h[(w * 16 + it) * 8];
-                    if (w >= NWC && FUSED) fprintf(stderr, "  loader %2d it %2d: t0=%6llu first pixel: C2 (blend, commit) %5llu C1 (consistency, history request) %5llu B %5llu A %5llu | second pixel %6llu | barrier %5llu\n", w, it,
+                    if (w >= NWC && FUSED != 0) fprintf(stderr, "  loader %2d it %2d: t0=%6llu first pixel: C2 (blend, commit) %5llu C1 (consistency, history request) %5llu B %5llu A %5llu | second pixel %6llu | barrier %5llu\n", w, it,
                                                    t[0] - h[0], t[1] - t[0], t[2] - t[1], t[3] - t[2], t[4] - t[3], t[5] - t[4], t[6] - t[5]);
                     else if (w >= NWC) fprintf(stderr, "  loader %2d it %2d: t0=%6llu work %6llu barrier %5llu\n", w, it, t[0] - h[0], t[5] - t[0], t[6] - t[5]);
                     else fprintf(stderr, "  wave %2d it %2d: t0=%6llu centre %5llu back rows %5llu own %5llu fwd rows %5llu out %5llu barrier %5llu\n", w, it,

@@ -16,12 +16,12 @@ hipError_t launch_reuse_step(const AtrousArgs &a, hipStream_t s)
     const int reuse = (a.tin ? 1 : 0) | (a.tout ? 2 : 0);
     if (!a.dst) {               // last level: no variance accumulators, nothing to hand on
         if (reuse != 1) return hipErrorInvalidValue;
-        return launch_lane_cfg<LOG2S, false, LOG2P, 0, false, 1>(a, s);
+        return launch_lane_cfg<LOG2S, false, LOG2P, 0, 0, 1>(a, s);
     }
     switch (reuse) {
-    case 1: return launch_lane_cfg<LOG2S, true, LOG2P, 0, false, 1>(a, s);
-    case 2: return launch_lane_cfg<LOG2S, true, LOG2P, 0, false, 2>(a, s);
-    case 3: return launch_lane_cfg<LOG2S, true, LOG2P, 0, false, 3>(a, s);
+    case 1: return launch_lane_cfg<LOG2S, true, LOG2P, 0, 0, 1>(a, s);
+    case 2: return launch_lane_cfg<LOG2S, true, LOG2P, 0, 0, 2>(a, s);
+    case 3: return launch_lane_cfg<LOG2S, true, LOG2P, 0, 0, 3>(a, s);
     default: return hipErrorInvalidValue;
     }
 }

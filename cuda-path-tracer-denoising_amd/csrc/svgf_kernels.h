@@ -93,6 +93,7 @@ struct TemporalArgs {
     float reproj_sx, reproj_sy;   // SvgfParams::reproj_scale; 0 = reference mapping
     const float *pos_prev;    // previous frame's positions (packed float3), read only when pos_tol > 0
     float pos_tol;            // SvgfParams::reproj_position_tol; 0 = the reference's consistency test
+    void *dump;               // fused kernel only: >= 4 KB of scrap the stores of pixels a workgroup does not own go to
 };
 
 hipError_t launch_temporal(const TemporalArgs &a, hipStream_t s, bool single_wave_blocks);
