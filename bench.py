@@ -276,6 +276,14 @@ def main():
             den.denoise(out, d_in[k], d_g[k], cams[k], params, stream=stream)
         return W * H
 
+    # Clock / power / temperature sampler (tools/telemetry.py): created and started BEFORE the warm-up.  Finding its hwmon node
+    # (a sysfs walk, a device-property query) takes milliseconds; between the warm-up and the timed region that was enough idle
+    # time for the GPU to leave its sustained power state, and the first timed frames paid the ramp back up: 0.266 -> 0.313 ms per
+    # step on the driver's 20-step command with identical kernels (profiles/r04_ab_bench_r03_vs_r04_tree.log, r04_bisect*.log).
+    # (SVGF_BENCH_NO_TELEMETRY=1: no sampler thread at all.)
+    tm_all = telemetry.Sampler(local_rank, period_s=float(os.environ.get("SVGF_BENCH_TELEMETRY_PERIOD", "0.005")))
+    if not os.environ.get("SVGF_BENCH_NO_TELEMETRY"):
+        tm_all.start()
     # warm-up is run with profiling slots too, then the frame counter restarts so slots hold the timed steps only
     t_w = time.perf_counter()
     n_w = 0
@@ -285,11 +293,8 @@ def main():
         if n_w % 32 == 0:
             torch.cuda.synchronize(dev)
     torch.cuda.synchronize(dev)
+    t_warm_end = time.perf_counter()
     den.profile_enable(a.steps)
-    # (SVGF_BENCH_NO_TELEMETRY=1: no sampler thread at all — the A/B that shows whether reading the hwmon nodes disturbs the run)
-    tm_all = telemetry.Sampler(local_rank, period_s=float(os.environ.get("SVGF_BENCH_TELEMETRY_PERIOD", "0.005")))
-    if not os.environ.get("SVGF_BENCH_NO_TELEMETRY"):
-        tm_all.start()
     t_region0 = time.perf_counter()
     dt, pixels = pkg.farm.timed_region(step, a.steps, 0, lambda: torch.cuda.synchronize(dev), dist=dist, device=None if share_device else dev)
     t_region1 = time.perf_counter()
@@ -370,6 +375,7 @@ def main():
                         "p10_ms": round(float(np.quantile(lat_ms, 0.1)), 5), "p90_ms": round(float(np.quantile(lat_ms, 0.9)), 5),
                         "mpixels_per_s": round(W * H / (float(np.median(lat_ms)) * 1e-3) / 1e6, 1),
                         "what": "wall time of svgf_denoise + svgf_sync per call (rank 0), what the reference's synchronous denoise() gives its caller"},
+            "idle_before_timed_region_ms": round((t_region0 - t_warm_end) * 1e3, 3),      # GPU idle between warm-up and timed steps
             "telemetry": {"timed_region": tm_all.summary(t_region0, t_region1), "latency_calls": tm_all.summary(t_lat0, t_lat1),
                           "isolated_16_frames": tm_all.summary(t_iso0, t_iso1)},
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",

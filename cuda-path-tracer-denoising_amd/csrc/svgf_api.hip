@@ -17,9 +17,9 @@
 
 #define SVGF_MAX_KERNELS_PER_FRAME (SVGF_MAX_LEVELS + 4)
 // a row of the fused temporal + first-level kernel against a row of the plain lane kernel, as measured at 1920x1080 (DESIGN.md
-// 5.8, profiles/r04_exp_fused_*.log: 225 us against 42.7 for the plain level, i.e. the fused kernel LOSES to temporal pass + level,
-// 57 + 49 us): with this factor the automatic choice never fuses; kernel_variant 6 forces it
-static const double kFusedRowFactor = 5.3;
+// 5.8, profiles/r04_exp_fused_*.log: 176 us in its last version against 42.7 for the plain level, i.e. the fused kernel LOSES to
+// temporal pass + level, 55 + 46 us): with this factor the automatic choice never fuses; kernel_variant 6 forces it
+static const double kFusedRowFactor = 4.1;
 
 struct svgf_ctx {
     int device, W, H;
@@ -29,6 +29,8 @@ struct svgf_ctx {
     unsigned vp_valid;     // bit k: vp[k] holds the variance of cv[k]
     int use_vplane;        // 0 only for A/B measurements (environment SVGF_NO_VARIANCE_PLANE at svgf_create)
     void *dump;            // 4 KB of scrap for the fused kernel (TemporalArgs::dump)
+    char *arena;           // the one allocation cv[], nrm[], gid[], mom[], hlen[], pos[] and dump are carved from
+    size_t arena_bytes;
     float4 *tp[2];         // cross-level reuse of the geometric terms: four terms per pixel, written by level L for level L+1 (lane kernels
                            // only, svgf_atrous_lane_reuse.hip); allocated when a frame first has two consecutive lane-kernel levels
     int use_reuse;         // 1 only for A/B measurements (environment SVGF_REUSE at svgf_create): measured a loss, profiles/r04_ab_reuse_*.log
@@ -126,34 +128,26 @@ extern "C" int svgf_params_default(SvgfParams *p)
     return SVGF_OK;
 }
 
-// History planes are allocated with kPlanePad bytes in front of and behind the W*H elements: the fused temporal + first-level
-// kernel reads the 3x3 window around a reprojected position as three 3-element row pieces, and a piece that starts one element
-// left of an image row's first pixel (or ends one right of its last) must stay inside the allocation at the plane's two ends.
-static const size_t kPlanePad = 128;
-static hipError_t plane_alloc(void **out, size_t bytes)
+// The context's planes live in ONE allocation (the arena), each with kPlanePad bytes in front of and behind its W*H elements:
+//   * the fused temporal + first-level kernel reads the 3x3 window around a reprojected position as three 3-element row
+//     pieces, and a piece that starts one element left of an image row's first pixel (or ends one right of its last) must stay
+//     inside memory the context owns at the plane's two ends;
+//   * it addresses every plane as arena + 32-bit byte offset (svgf_atrous_lane_impl.h: LaneFused), which needs them within
+//     4 GiB of one base — true by construction up to the sizes atrous_fused_supported() admits.
+static const size_t kPlanePad = 128, kPlaneAlign = 4096;
+static size_t plane_span(size_t bytes) { return (bytes + 2 * kPlanePad + kPlaneAlign - 1) / kPlaneAlign * kPlaneAlign; }
+static void *plane_carve(svgf_ctx *c, size_t *cursor, size_t bytes)
 {
-    char *raw = nullptr;
-    hipError_t e = hipMalloc((void **)&raw, bytes + 2 * kPlanePad);
-    if (e != hipSuccess) { *out = nullptr; return e; }
-    e = hipMemset(raw, 0, bytes + 2 * kPlanePad);
-    *out = raw + kPlanePad;
-    return e;
+    char *p = c->arena + *cursor + kPlanePad;
+    *cursor += plane_span(bytes);
+    return p;
 }
-static void plane_free(void *p) { if (p) (void)hipFree((char *)p - kPlanePad); }
 
 static void free_all(svgf_ctx *c)
 {
-    for (int k = 0; k < 3; k++) plane_free(c->cv[k]);
+    if (c->arena) (void)hipFree(c->arena);          // cv[], nrm[], gid[], mom[], hlen[], pos[], dump
     for (int k = 0; k < 3; k++) if (c->vp[k]) (void)hipFree(c->vp[k]);
     for (int k = 0; k < 2; k++) if (c->tp[k]) (void)hipFree(c->tp[k]);
-    if (c->dump) (void)hipFree(c->dump);
-    for (int k = 0; k < 2; k++) {
-        plane_free(c->nrm[k]);
-        plane_free(c->gid[k]);
-        plane_free(c->mom[k]);
-        plane_free(c->hlen[k]);
-    }
-    for (int k = 0; k < 2; k++) plane_free(c->pos[k]);
     if (c->albedo) (void)hipFree(c->albedo);
     if (c->cv_capture) (void)hipFree(c->cv_capture);
     if (c->st_in) (void)hipFree(c->st_in);
@@ -214,17 +208,27 @@ extern "C" int svgf_create(int device, int width, int height, svgf_ctx **out)
     memset(c->lane_cheaper, -1, sizeof(c->lane_cheaper));
     c->fuse_pays = -1;
     bool ok = true;
-    for (int k = 0; k < 3 && ok; k++) ok = plane_alloc((void **)&c->cv[k], c->n * sizeof(float4)) == hipSuccess;
-    ok = ok && hipMalloc(&c->dump, 4096) == hipSuccess;
+    {
+        const size_t n = c->n;
+        c->arena_bytes = 3 * plane_span(n * sizeof(float4)) + 2 * (2 * plane_span(n * 3 * sizeof(float)) + 2 * plane_span(n * sizeof(int)) + plane_span(n * sizeof(float2)))
+                         + plane_span(4096);
+        ok = hipMalloc((void **)&c->arena, c->arena_bytes) == hipSuccess && hipMemset(c->arena, 0, c->arena_bytes) == hipSuccess;
+        if (ok) {
+            size_t cur = 0;
+            for (int k = 0; k < 3; k++) c->cv[k] = (float4 *)plane_carve(c, &cur, n * sizeof(float4));
+            for (int k = 0; k < 2; k++) {
+                c->nrm[k] = (float *)plane_carve(c, &cur, n * 3 * sizeof(float));
+                c->gid[k] = (int *)plane_carve(c, &cur, n * sizeof(int));
+                c->mom[k] = (float2 *)plane_carve(c, &cur, n * sizeof(float2));
+                c->hlen[k] = (int *)plane_carve(c, &cur, n * sizeof(int));
+                c->pos[k] = (float *)plane_carve(c, &cur, n * 3 * sizeof(float));
+            }
+            c->dump = plane_carve(c, &cur, 4096);
+            if (cur != c->arena_bytes) ok = false;         // (the size formula above and the carving below it disagree)
+        }
+    }
     // (+64 bytes: the step-16/32 lane kernel reads the variance plane in 16-byte pieces that may end 8 bytes behind the last margin)
     for (int k = 0; k < 3 && ok; k++) ok = hipMalloc((void **)&c->vp[k], (size_t)(width + 2) * (height + 2) * sizeof(float) + 64) == hipSuccess;
-    for (int k = 0; k < 2 && ok; k++) {
-        ok = ok && plane_alloc((void **)&c->nrm[k], c->n * 3 * sizeof(float)) == hipSuccess;
-        ok = ok && plane_alloc((void **)&c->gid[k], c->n * sizeof(int)) == hipSuccess;
-        ok = ok && plane_alloc((void **)&c->mom[k], c->n * sizeof(float2)) == hipSuccess;
-        ok = ok && plane_alloc((void **)&c->hlen[k], c->n * sizeof(int)) == hipSuccess;
-        ok = ok && plane_alloc((void **)&c->pos[k], c->n * 3 * sizeof(float)) == hipSuccess;
-    }
     if (!ok) {
         snprintf(g_create_err, sizeof(g_create_err), "svgf_create: hipMalloc failed for %dx%d", width, height);
         free_all(c); delete c;
@@ -478,7 +482,7 @@ static int denoise_frame(svgf_ctx *c, void *out_rgb_dev, const void *in_rgb_dev,
         t.W = c->W; t.H = c->H; t.color_alpha_min = p->color_alpha; t.moment_alpha_min = p->moment_alpha;
         t.reproj_sx = p->reproj_scale[0]; t.reproj_sy = p->reproj_scale[1];
         t.pos_prev = c->pos[c->gcur]; t.pos_tol = p->reproj_position_tol;
-        t.dump = c->dump;
+        t.dump = c->dump; t.arena = c->arena; t.arena_bytes = c->arena_bytes;
         if (cascade && (p->kernel_variant == 0 || p->kernel_variant == 6) && !p->paper_steps && p->spatial_variance_frames <= 0) {
             AtrousArgs probe;
             memset(&probe, 0, sizeof(probe));

@@ -15,12 +15,47 @@
 // geometry costs from what the fusion brings.
 #include "svgf_atrous_lane_impl.h"
 
+// byte offset of a context plane from the context's allocation; false when it does not fit 32 bits
+static bool arena_offset(const TemporalArgs &t, const void *plane, long long bias, size_t extent, unsigned *out)
+{
+    if (!t.arena || !plane) return false;
+    const long long off = (const char *)plane - (const char *)t.arena + bias;
+    if (off < 0 || (unsigned long long)off + extent > (unsigned long long)t.arena_bytes || (unsigned long long)off + extent >= (1ULL << 32)) return false;
+    *out = (unsigned)off;
+    return true;
+}
+
+static bool fused_offsets(const TemporalArgs &t, LaneFused *f)
+{
+    static_cast<TemporalArgs &>(*f) = t;
+    const size_t n = (size_t)t.W * t.H;
+    bool ok = true;
+    // taps: element index + 2 (t_window), up to two elements beyond either end of the plane (the planes' padding)
+    ok = ok && arena_offset(t, t.cv_hist, -2 * 16, (n + 4) * 16, &f->o_cv_hist);
+    ok = ok && arena_offset(t, t.mom_hist, -2 * 8, (n + 4) * 8, &f->o_mom_hist);
+    ok = ok && arena_offset(t, t.hlen, -2 * 4, (n + 4) * 4, &f->o_hlen);
+    ok = ok && arena_offset(t, t.gid_prev, -2 * 4, (n + 4) * 4, &f->o_gid_prev);
+    ok = ok && arena_offset(t, t.nrm_prev, -2 * 12, (n + 4) * 12, &f->o_nrm_prev);
+    ok = ok && arena_offset(t, t.hlen_upd, 0, n * 4, &f->o_hlen_upd);
+    ok = ok && arena_offset(t, t.mom_acc, 0, n * 8, &f->o_mom_acc);
+    ok = ok && arena_offset(t, t.dump, 0, 4096, &f->o_dump);
+    if (t.cv_acc) ok = ok && arena_offset(t, t.cv_acc, 0, n * 16, &f->o_cv_acc);
+    else f->o_cv_acc = f->o_dump;
+    if (t.gbuf) {                  // the AoS path splits the G-buffer into the context's planes
+        ok = ok && arena_offset(t, t.nrm_cur, 0, n * 12, &f->o_nrm_cur);
+        ok = ok && arena_offset(t, t.pos_cur, 0, n * 12, &f->o_pos_cur);
+        ok = ok && arena_offset(t, t.gid_cur, 0, n * 4, &f->o_gid_cur);
+    } else f->o_nrm_cur = f->o_pos_cur = f->o_gid_cur = f->o_dump;
+    return ok;
+}
+
 bool atrous_fused_supported(const AtrousArgs &a, const TemporalArgs &t)
 {
     if (a.step != 2) return false;                                   // the reference's first level (src/denoise.cu:98,386)
-    if ((long long)a.W * a.H * 52 >= (1LL << 32)) return false;      // 32-bit byte offsets, the AoS texel being the widest element
+    if ((long long)a.W * a.H + 8 >= (1LL << 24)) return false;       // 24-bit element indices (v_mad_u32_u24), 32-bit byte offsets
     if (t.pos_tol > 0.0f) return false;                              // f4 extension, k_temporal only
-    return true;
+    LaneFused f;
+    return fused_offsets(t, &f);                                     // every plane inside the context's one allocation
 }
 
 double atrous_fused_estimate_us(const AtrousArgs &a, int n_cu)
@@ -32,9 +67,10 @@ double atrous_fused_estimate_us(const AtrousArgs &a, int n_cu)
 hipError_t launch_atrous_fused(const AtrousArgs &a, const TemporalArgs &t, hipStream_t s)
 {
     if (a.step != 2) return hipErrorInvalidValue;
-    if (!t.dump) return hipErrorInvalidValue;
-    if (t.gbuf) return a.dst ? launch_lane_cfg<1, true, 1, 1, 1>(a, s, &t) : launch_lane_cfg<1, false, 1, 1, 1>(a, s, &t);
-    return a.dst ? launch_lane_cfg<1, true, 1, 1, 2>(a, s, &t) : launch_lane_cfg<1, false, 1, 1, 2>(a, s, &t);
+    LaneFused f;
+    if (!t.dump || !fused_offsets(t, &f)) return hipErrorInvalidValue;
+    if (t.gbuf) return a.dst ? launch_lane_cfg<1, true, 1, 1, 1>(a, s, &f) : launch_lane_cfg<1, false, 1, 1, 1>(a, s, &f);
+    return a.dst ? launch_lane_cfg<1, true, 1, 1, 2>(a, s, &f) : launch_lane_cfg<1, false, 1, 1, 2>(a, s, &f);
 }
 
 // step 2 with both y-phases in one workgroup, not fused (reads the accumulated plane like every other level)

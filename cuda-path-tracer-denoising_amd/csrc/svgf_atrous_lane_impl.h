@@ -118,6 +118,14 @@ __device__ __forceinline__ float lane_from(float v)
 // the temporal pass be fused into this level (FUSED): the loader waves PRODUCE the rows they stage (svgf_temporal.h, the
 // arithmetic of k_temporal) instead of loading them, and the accumulated variance of rows y +- 1 exists nowhere but in the ring.
 struct LaneNoTemporal {};
+// FUSED: the temporal pass's arguments plus, for every plane of the context the fused stages address PER LANE (history taps, the
+// stores of owned / not-owned pixels), its byte offset from the context's one allocation (TemporalArgs::arena): a per-lane choice
+// between two planes is then a 32-bit select on offsets over ONE scalar base, not a 64-bit select between two pointers.  The
+// read offsets carry the "- 2 elements" of t_window() already.
+struct LaneFused : TemporalArgs {
+    unsigned o_cv_hist, o_mom_hist, o_hlen, o_gid_prev, o_nrm_prev;                              // history taps (element - 2)
+    unsigned o_hlen_upd, o_mom_acc, o_cv_acc, o_nrm_cur, o_pos_cur, o_gid_cur, o_dump;          // stores (cv_acc = dump when unwanted)
+};
 //
 // REUSE (round 4): the geometric part of a pair's exponent, g(p, q) = kn |n_p - n_q| + kx |x_p - x_q|, does not depend on the
 // level, and the pairs at lattice offsets (+2, 0), (-2, +2), (0, +2), (+2, +2) of step S ARE the pairs at offsets (+1, 0), (-1, +1),
@@ -133,7 +141,7 @@ struct LaneNoTemporal {};
 // half idle.  Off by default (environment SVGF_REUSE=1 turns it on); kept because it is correct and small.
 // FUSED: 0 no, 1 fused temporal pass reading the AoS G-buffer, 2 fused temporal pass reading the producer's planes
 template <int LOG2S, bool HASVAR, int LOG2P = LOG2S, int LOG2Y = 0, int FUSED = 0, int REUSE = 0>
-__global__ __launch_bounds__(NT) void k_atrous_lane(AtrousArgs a, LaneGeom gm, std::conditional_t<FUSED != 0, TemporalArgs, LaneNoTemporal> ta)
+__global__ __launch_bounds__(NT) void k_atrous_lane(AtrousArgs a, LaneGeom gm, std::conditional_t<FUSED != 0, LaneFused, LaneNoTemporal> ta)
 {
     constexpr bool REUSE_IN = (REUSE & 1) != 0, REUSE_OUT = (REUSE & 2) != 0;
     constexpr int S = 1 << LOG2S;
@@ -448,7 +456,7 @@ __global__ __launch_bounds__(NT) void k_atrous_lane(AtrousArgs a, LaneGeom gm, s
     // What a pixel carries from stage to stage is kept small on purpose — the loader waves have the 168 registers three waves
     // per SIMD leave: the colour is fetched in stage C rather than in A (3 registers), ring record and pixel index are re-derived.
     // ====================================================================================================================
-    struct TA_ { float nx, ny, nz, px, py, pz; int gid, N; };                         // stage A: primary data
+    struct TAu_ { float nx, ny, nz, px, py, pz; int gid, N; };                        // stage A's data as the later stages use it
     // Carried values keep the SHAPE of the loads that fetch them (vector types, one per load instruction): a scalar array filled
     // from a wide load makes the register allocator load into a scratch tuple and copy — behind an s_waitcnt for a load it has
     // just issued (r04_exp_fused_v7: two exposed round trips per sub-step in stage B alone).  The pointer types say "4-byte
@@ -459,6 +467,12 @@ __global__ __launch_bounds__(NT) void k_atrous_lane(AtrousArgs a, LaneGeom gm, s
     typedef v3f __attribute__((aligned(4))) v3f_u;
     typedef v4f __attribute__((aligned(4))) v4f_u;
     typedef v2i __attribute__((aligned(4))) v2i_u;
+    // stage A as loaded: AoS texel = floats 0..3 {nx, ny, nz, px} + 4..5 {py, pz} + geomId; planes = normal + position + geomId
+    struct TA_ { v4f g4; v2f g2; v3f n3, q3; int gid, N; };
+    [[maybe_unused]] auto t_unpack = [](const TA_ &t) -> TAu_ {
+        if constexpr (FUSED == 1) return TAu_{ t.g4.x, t.g4.y, t.g4.z, t.g4.w, t.g2.x, t.g2.y, t.gid, t.N };
+        else return TAu_{ t.n3.x, t.n3.y, t.n3.z, t.q3.x, t.q3.y, t.q3.z, t.gid, t.N };
+    };
     // stage B: the bilinear quad, one row piece per window row yy = 0, 1: geomId of taps (0, yy), (1, yy); their normals as 4 + 2 floats
     struct TB_ { v2i g[2]; v4f n4[2]; v2f n2[2]; };
     // Stage C1's request, ONE static shape of nine loads whatever the pixel needs (a load count that depended on the pixel would
@@ -469,18 +483,41 @@ __global__ __launch_bounds__(NT) void k_atrous_lane(AtrousArgs a, LaneGeom gm, s
     // (0, yy), (1, yy) | h4[0].xyz = geomIds of window row -1; h2[yy] = history lengths of those two taps | h2[yy].x = geomId of
     // window tap 3 (yy = 0), 6 (yy = 1))
     struct TC_ { v3f h3[5]; v4f h4[2]; v2f h2[2]; v3f rgb; SvgfReproj rp; int mode, m9; };
-    // Element index (+ 2) of the 3x3 window's row yy (-1, 0, 1), first column (fx - 1).  Rows are clamped into the image, the
-    // first column into [-2, W - 1]: a window with any tap on screen has fx in [-1, W] and is read where it lies — its off-screen
-    // taps fall at most two elements outside a row, i.e. inside the planes' padding at the two ends of a plane (svgf_api.hip:
-    // kPlanePad) — and every tap's validity comes from svgf_tap_index() on the float coordinates, never from the address.
-    // The + 2 makes it a non-negative offset from (plane - 2 elements).
-    [[maybe_unused]] auto t_window_row = [&](float fx, float fy, int yy) -> unsigned {
-        const float fxc = fminf(fmaxf(fx, -1.0f), (float)W);              // NaN -> -1
-        const float fyc = fminf(fmaxf(fy + (float)yy, 0.0f), (float)(H - 1));
-        return (unsigned)((int)fyc * W + ((int)fxc + 1));
+    // The 3x3 window around the reprojected position (fx, fy): element index (+ 2) of the first column (fx - 1) of its rows
+    // fy - 1, fy, fy + 1.  Rows are clamped into the image, the first column into [-2, W - 1]: a window with any tap on screen has
+    // fx in [-1, W] and is read where it lies — its off-screen taps fall at most two elements outside a row, i.e. inside the
+    // planes' padding at the two ends of a plane (svgf_api.hip: kPlanePad) — and every tap's validity comes from t_on_screen()
+    // on the same coordinates, never from the address.  The + 2 makes it a non-negative offset from (plane - 2 elements).
+    // Integer arithmetic on (fx, fy) clamped to [-2, W + 1] x [-2, H + 1] (NaN -> -2): exact for every window that has a tap on
+    // screen, and all the others only need SOME address inside the plane.
+    struct TWin_ { int ix, iy; unsigned em, e0, e1; };
+    [[maybe_unused]] auto t_window = [&](float fx, float fy) -> TWin_ {
+        TWin_ w;
+        w.ix = (int)fminf(fmaxf(fx, -2.0f), (float)(W + 1));
+        w.iy = (int)fminf(fmaxf(fy, -2.0f), (float)(H + 1));
+        const int col = min(max(w.ix, -1), W) + 1;
+        w.em = (unsigned)(__mul24(min(max(w.iy - 1, 0), H - 1), W) + col);      // (W * H < 2^24: atrous_fused_supported)
+        w.e0 = (unsigned)(__mul24(min(max(w.iy, 0), H - 1), W) + col);
+        w.e1 = (unsigned)(__mul24(min(max(w.iy + 1, 0), H - 1), W) + col);
+        return w;
     };
-    [[maybe_unused]] auto t_at = [](const void *plane, unsigned elem_plus_2, unsigned elem_bytes) -> const char * {
-        return reinterpret_cast<const char *>(plane) - 2 * (long)elem_bytes + elem_plus_2 * elem_bytes;
+    // Taps of the window on screen (the bounds part of isReprjValid, :173-176; svgf_tap_index() >= 0 for the nine taps), bit
+    // (yy + 1) * 3 + (xx + 1).  Separable: bit k of span3(i, n) says 0 <= i + k - 1 < n.  With i clamped to [-2, n + 1] as above
+    // the answer is the one the float comparisons of svgf_tap_index() give: inside the clamp range fx + xx is exact, outside it
+    // (and for NaN, which the clamp sends to -2) no tap of that axis is on screen.
+    [[maybe_unused]] auto t_on_screen = [&](const TWin_ &w) -> int {
+        auto span3 = [](int i, int n) { return (7 << min(max(1 - i, 0), 3)) & (7 >> (2 - min(n - i, 2))) & 7; };
+        const int mx = span3(w.ix, W), my = span3(w.iy, H);
+        return (mx * 0x49) & (((my & 1) | ((my & 2) << 2) | ((my & 4) << 4)) * 7);
+    };
+    // history planes are addressed as (the context's allocation) + 32-bit byte offset, see LaneFused
+    [[maybe_unused]] auto t_ptr = [&](unsigned byte_off) -> const char * {
+        if constexpr (FUSED != 0) return reinterpret_cast<const char *>(ta.arena) + byte_off;
+        else return nullptr;
+    };
+    [[maybe_unused]] auto t_wptr = [&](unsigned byte_off) -> char * {
+        if constexpr (FUSED != 0) return const_cast<char *>(reinterpret_cast<const char *>(ta.arena)) + byte_off;
+        else return nullptr;
     };
     constexpr int kLdsDump = RING_BYTES + 32;          // 48 bytes nobody reads: the ring record of a thread's idle pixel slot
     // pixel (lattice row br, y-phase yp, staged column xi) -> ring record, pixel index, flags (1: inside the image, 2: owned)
@@ -497,49 +534,49 @@ __global__ __launch_bounds__(NT) void k_atrous_lane(AtrousArgs a, LaneGeom gm, s
         if constexpr (FUSED != 0) {
             // (unsigned 32-bit byte offsets: scalar base + vector offset addressing; W * H * 52 < 2^32 is checked by the launcher)
             if constexpr (FUSED == 1) {         // the boundary's AoS texels
-                const float *g = reinterpret_cast<const float *>(reinterpret_cast<const char *>(ta.gbuf) + p * 52u);
-                t.nx = g[0]; t.ny = g[1]; t.nz = g[2]; t.px = g[3]; t.py = g[4]; t.pz = g[5];
-                t.gid = __float_as_int(g[12]);
+                const char *g = reinterpret_cast<const char *>(ta.gbuf) + __umul24(p, 52u);
+                t.g4 = *reinterpret_cast<const v4f_u *>(g);
+                t.g2 = *reinterpret_cast<const v2f_u *>(g + 16);
+                t.gid = *reinterpret_cast<const int *>(g + 48);
             } else {                            // planes written in place by the producer (svgf_planar_gbuffer)
-                const float *n = reinterpret_cast<const float *>(reinterpret_cast<const char *>(ta.nrm_cur) + p * 12u);
-                const float *q = reinterpret_cast<const float *>(reinterpret_cast<const char *>(ta.pos_cur) + p * 12u);
-                t.nx = n[0]; t.ny = n[1]; t.nz = n[2]; t.px = q[0]; t.py = q[1]; t.pz = q[2];
+                t.n3 = *reinterpret_cast<const v3f_u *>(reinterpret_cast<const char *>(ta.nrm_cur) + __umul24(p, 12u));
+                t.q3 = *reinterpret_cast<const v3f_u *>(reinterpret_cast<const char *>(ta.pos_cur) + __umul24(p, 12u));
                 t.gid = *reinterpret_cast<const int *>(reinterpret_cast<const char *>(ta.gid_cur) + p * 4u);
             }
             t.N = *reinterpret_cast<const int *>(reinterpret_cast<const char *>(ta.hlen) + p * 4u);
         }
     };
     // history lookup wanted (:197): the pixel is inside the image, has a history and hit something
-    [[maybe_unused]] auto t_wants_history = [&](const TA_ &a_, int flags) { return (flags & 1) && a_.N > 0 && a_.gid != -1; };
+    [[maybe_unused]] auto t_wants_history = [&](const TAu_ &a_, int flags) { return (flags & 1) && a_.N > 0 && a_.gid != -1; };
     // (unconditional: a pixel that wants no history reprojects whatever its position is — NaN included — and reads clamped
     // addresses; nothing of it is used)
-    [[maybe_unused]] auto t_stage_b = [&](const TA_ &a_, TB_ &b_, SvgfReproj &rp_out) __attribute__((always_inline)) {
+    [[maybe_unused]] auto t_stage_b = [&](const TA_ &araw, TB_ &b_, SvgfReproj &rp_out) __attribute__((always_inline)) {
         if constexpr (FUSED != 0) {
+            const TAu_ a_ = t_unpack(araw);
             const SvgfReproj rp = svgf_reproject(ta, a_.px, a_.py, a_.pz);
             rp_out = rp;
+            const TWin_ w = t_window(rp.fx, rp.fy);
 #pragma unroll
             for (int yy = 0; yy <= 1; yy++) {                             // the bilinear quad: taps (0, yy), (1, yy), one row piece each
-                const unsigned e = t_window_row(rp.fx, rp.fy, yy) + 1u;
-                const char *np = t_at(ta.nrm_prev, e, 12u);
-                b_.g[yy] = *reinterpret_cast<const v2i_u *>(t_at(ta.gid_prev, e, 4u));
+                const unsigned e = (yy ? w.e1 : w.e0) + 1u;
+                const char *np = t_ptr(ta.o_nrm_prev + __umul24(e, 12u));
+                b_.g[yy] = *reinterpret_cast<const v2i_u *>(t_ptr(ta.o_gid_prev + e * 4u));
                 b_.n4[yy] = *reinterpret_cast<const v4f_u *>(np);
                 b_.n2[yy] = *reinterpret_cast<const v2f_u *>(np + 16);
             }
         }
     };
-    [[maybe_unused]] auto t_stage_c1 = [&](const TA_ &a_, const TB_ &b_, const SvgfReproj &rp, int flags, unsigned p, TC_ &c_) __attribute__((always_inline)) {
+    [[maybe_unused]] auto t_stage_c1 = [&](const TA_ &araw, const TB_ &b_, const SvgfReproj &rp, int flags, unsigned p, TC_ &c_) __attribute__((always_inline)) {
         if constexpr (FUSED != 0) {
-            c_.rgb = *reinterpret_cast<const v3f_u *>(reinterpret_cast<const char *>(ta.in_rgb) + p * 12u);
+            const TAu_ a_ = t_unpack(araw);
+            c_.rgb = *reinterpret_cast<const v3f_u *>(reinterpret_cast<const char *>(ta.in_rgb) + __umul24(p, 12u));
             c_.rp = rp;
             const bool wants = t_wants_history(a_, flags);
-            int m9 = 0;                                                   // taps on screen (:173-176), bit (yy + 1) * 3 + xx + 1
-#pragma unroll
-            for (int k = 0; k < 9; k++)
-                m9 |= (svgf_tap_index(ta, rp.fx + (float)(k % 3 - 1), rp.fy + (float)(k / 3 - 1)) >= 0) ? (1 << k) : 0;
-            m9 = wants ? m9 : 0;
+            const TWin_ w = t_window(rp.fx, rp.fy);
+            int m9 = wants ? t_on_screen(w) : 0;                          // taps on screen (:173-176), bit (yy + 1) * 3 + xx + 1
             // the bilinear quad: window taps 4, 5, 7, 8; its geomIds and normals are here: consistency test (:177-180)
             constexpr int quad[4] = { 4, 5, 7, 8 };
-            bool all = wants & (rp.fx >= 0.0f) & (rp.fy >= 0.0f) & (rp.fx < (float)W) & (rp.fy < (float)H);
+            bool all = wants;                                             // (tap 4 on screen is fx, fy inside the image, :230)
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 const int yy = k >> 1;
@@ -551,31 +588,31 @@ __global__ __launch_bounds__(NT) void k_atrous_lane(AtrousArgs a, LaneGeom gm, s
             }
             c_.m9 = m9;
             c_.mode = wants ? (all ? 1 : 2) : 0;
-            const unsigned em = t_window_row(rp.fx, rp.fy, -1), e0 = t_window_row(rp.fx, rp.fy, 0), e1 = t_window_row(rp.fx, rp.fy, 1);
+            const unsigned em = w.em, e0 = w.e0, e1 = w.e1;
             // five 12-byte pieces: the quad's history colours, or the normals of window taps 0, 1, 2, 3, 6
 #pragma unroll
             for (int k = 0; k < 5; k++) {
-                const char *hist = t_at(ta.cv_hist, (k < 2 ? e0 : e1) + 1u + (unsigned)(k & 1), 16u);
-                const char *nrmp = t_at(ta.nrm_prev, k < 3 ? em + (unsigned)k : (k == 3 ? e0 : e1), 12u);
-                c_.h3[k] = *reinterpret_cast<const v3f_u *>((all && k < 4) ? hist : nrmp);
+                const unsigned hist = ta.o_cv_hist + ((k < 2 ? e0 : e1) + 1u + (unsigned)(k & 1)) * 16u;
+                const unsigned nrmp = ta.o_nrm_prev + __umul24(k < 3 ? em + (unsigned)k : (k == 3 ? e0 : e1), 12u);
+                c_.h3[k] = *reinterpret_cast<const v3f_u *>(t_ptr((all && k < 4) ? hist : nrmp));
             }
             // two 16-byte pieces: the quad's history moments (two taps a row), or the geomIds of window row -1
 #pragma unroll
-            for (int yy = 0; yy <= 1; yy++) {
-                c_.h4[yy] = *reinterpret_cast<const v4f_u *>(all ? t_at(ta.mom_hist, (yy ? e1 : e0) + 1u, 8u) : t_at(ta.gid_prev, em, 4u));
-            }
+            for (int yy = 0; yy <= 1; yy++)
+                c_.h4[yy] = *reinterpret_cast<const v4f_u *>(t_ptr(all ? ta.o_mom_hist + ((yy ? e1 : e0) + 1u) * 8u : ta.o_gid_prev + em * 4u));
             // two 8-byte pieces: the quad's history lengths, or the geomIds of window taps 3 and 6 (first element)
 #pragma unroll
-            for (int yy = 0; yy <= 1; yy++) {
-                c_.h2[yy] = *reinterpret_cast<const v2f_u *>(all ? t_at(ta.hlen, (yy ? e1 : e0) + 1u, 4u) : t_at(ta.gid_prev, yy ? e1 : e0, 4u));
-            }
+            for (int yy = 0; yy <= 1; yy++)
+                c_.h2[yy] = *reinterpret_cast<const v2f_u *>(t_ptr((all ? ta.o_hlen + 4u : ta.o_gid_prev) + (yy ? e1 : e0) * 4u));
         }
     };
-    [[maybe_unused]] auto t_stage_c2 = [&](const TA_ &a_, const TC_ &c_, int flags, unsigned p, int lds_off) __attribute__((always_inline)) {
+    [[maybe_unused]] auto t_stage_c2 = [&](const TA_ &araw, const TC_ &c_, int flags, unsigned p, int lds_off) __attribute__((always_inline)) {
         if constexpr (FUSED != 0) {
+            const TAu_ a_ = t_unpack(araw);
             const float lum = svgf_lum_strict(c_.rgb.x, c_.rgb.y, c_.rgb.z);
             SvgfHistSum hs = { 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f };
-            bool valid = false;
+            bool valid = false, do_div = false;       // one division of the six sums, whichever path filled them
+            float dsum = 0.0f;
             if (c_.mode == 1) {                                       // bilinear (:234-259)
                 float w[4];
                 svgf_bilinear_weights(c_.rp.fracx, c_.rp.fracy, w);
@@ -588,7 +625,7 @@ __global__ __launch_bounds__(NT) void k_atrous_lane(AtrousArgs a, LaneGeom gm, s
                                            __float_as_int(right ? c_.h2[yy].y : c_.h2[yy].x));
                     sumw += w[k];
                 }
-                if ((double)sumw >= 0.01) svgf_hist_div(hs, sumw);
+                dsum = sumw; do_div = (double)sumw >= 0.01;
                 valid = true;
             } else if (c_.mode == 2) {                                // 3x3 box around floor (:262-286)
                 int m9 = c_.m9;
@@ -606,10 +643,11 @@ __global__ __launch_bounds__(NT) void k_atrous_lane(AtrousArgs a, LaneGeom gm, s
                     for (int yy = -1; yy <= 1; yy++) {
                         const int mrow = (m9 >> ((yy + 1) * 3)) & 7;
                         if (mrow) {
-                            const unsigned e = t_window_row(c_.rp.fx, c_.rp.fy, yy);
-                            const float *ch = reinterpret_cast<const float *>(t_at(ta.cv_hist, e, 16u));
-                            const float *m = reinterpret_cast<const float *>(t_at(ta.mom_hist, e, 8u));
-                            const int *l = reinterpret_cast<const int *>(t_at(ta.hlen, e, 4u));
+                            const TWin_ w = t_window(c_.rp.fx, c_.rp.fy);
+                            const unsigned e = yy < 0 ? w.em : (yy == 0 ? w.e0 : w.e1);
+                            const float *ch = reinterpret_cast<const float *>(t_ptr(ta.o_cv_hist + e * 16u));
+                            const float *m = reinterpret_cast<const float *>(t_ptr(ta.o_mom_hist + e * 8u));
+                            const int *l = reinterpret_cast<const int *>(t_ptr(ta.o_hlen + e * 4u));
                             float c3[3][3], mo3[3][2];
                             int l3[3];
 #pragma unroll
@@ -623,10 +661,11 @@ __global__ __launch_bounds__(NT) void k_atrous_lane(AtrousArgs a, LaneGeom gm, s
                                 if ((mrow >> xx) & 1) { svgf_hist_add(hs, c3[xx][0], c3[xx][1], c3[xx][2], mo3[xx][0], mo3[xx][1], l3[xx]); cnt += 1.0f; }
                         }
                     }
-                    svgf_hist_div(hs, cnt);
+                    dsum = cnt; do_div = true;
                     valid = true;
                 }
             }
+            if (do_div) svgf_hist_div(hs, dsum);
             const SvgfTemporalOut o = svgf_temporal_blend(ta, c_.rgb.x, c_.rgb.y, c_.rgb.z, lum, a_.N, valid, hs);
             // ring record, as rows_store() writes it (an idle slot's goes to kLdsDump)
             const bool ok = (flags & 1) != 0;
@@ -641,16 +680,16 @@ __global__ __launch_bounds__(NT) void k_atrous_lane(AtrousArgs a, LaneGeom gm, s
             // issues every store — a pixel that is not owned stores into a scrap buffer (ta.dump) — so that the NUMBER of
             // vector-memory operations of a sub-step does not depend on the pixel (see the pipeline below).
             const bool owned = (flags & 2) != 0;
-            char *scrap = reinterpret_cast<char *>(ta.dump) + (tid & 255) * 16;
-            *reinterpret_cast<int *>(owned ? reinterpret_cast<char *>(ta.hlen_upd) + p * 4u : scrap) = o.hlen;
-            *reinterpret_cast<float2 *>(owned ? reinterpret_cast<char *>(ta.mom_acc) + p * 8u : scrap) = o.mom;
-            // (the accumulated plane itself: only when something besides this level reads it)
-            *reinterpret_cast<float4 *>((owned && ta.cv_acc) ? reinterpret_cast<char *>(ta.cv_acc) + p * 16u : scrap) = o.cv;
+            const unsigned scrap = ta.o_dump + (unsigned)(tid & 255) * 16u;
+            *reinterpret_cast<int *>(t_wptr(owned ? ta.o_hlen_upd + p * 4u : scrap)) = o.hlen;
+            *reinterpret_cast<float2 *>(t_wptr(owned ? ta.o_mom_acc + p * 8u : scrap)) = o.mom;
+            // (the accumulated plane itself: only when something besides this level reads it — else o_cv_acc is the scrap buffer)
+            *reinterpret_cast<float4 *>(t_wptr(owned ? ta.o_cv_acc + (ta.cv_acc ? p * 16u : (unsigned)(tid & 255) * 16u) : scrap)) = o.cv;
             if constexpr (FUSED == 1) {
-                float *n = reinterpret_cast<float *>(owned ? reinterpret_cast<char *>(ta.nrm_cur) + p * 12u : scrap);
-                float *q = reinterpret_cast<float *>(owned ? reinterpret_cast<char *>(ta.pos_cur) + p * 12u : scrap);
+                float *n = reinterpret_cast<float *>(t_wptr(owned ? ta.o_nrm_cur + __umul24(p, 12u) : scrap));
+                float *q = reinterpret_cast<float *>(t_wptr(owned ? ta.o_pos_cur + __umul24(p, 12u) : scrap));
                 n[0] = a_.nx; n[1] = a_.ny; n[2] = a_.nz; q[0] = a_.px; q[1] = a_.py; q[2] = a_.pz;
-                *reinterpret_cast<int *>(owned ? reinterpret_cast<char *>(ta.gid_cur) + p * 4u : scrap) = a_.gid;
+                *reinterpret_cast<int *>(t_wptr(owned ? ta.o_gid_cur + p * 4u : scrap)) = a_.gid;
             }
         }
     };
@@ -691,6 +730,20 @@ __global__ __launch_bounds__(NT) void k_atrous_lane(AtrousArgs a, LaneGeom gm, s
             }
             t_describe(br, yp, xi, active, lo, p, fl);
         };
+        // The loop's pixels (q >= 4) differ only by their row: what depends on the thread is computed once.  l_flags: bit 0 the
+        // column is inside the image, bit 1 it is one of the workgroup's output columns (0 for a thread without a column).
+        const int l_xs = xs_of(lxi);
+        const unsigned l_xsc = (unsigned)min(max(l_xs, 0), W - 1);
+        const int l_rec = rec_of(lxi);
+        const int l_flags = (lactive && l_xs >= 0 && l_xs < W) ? (1 | ((lxi >= 2 * S && lxi < 2 * S + TXW) ? 2 : 0)) : 0;
+        auto describe_loop_px = [&](int q, int &lo, unsigned &p, int &fl) __attribute__((always_inline)) {
+            const int br = b0 + 3 + ((q - 4) >> 1), yp = q & 1;                 // wave-uniform, like everything derived from them
+            const int y = phase + yp + (br << LOG2S);
+            const bool row_live = br <= b1 + 1;
+            fl = l_flags & ((row_live && y < H) ? (br < b1 ? 3 : 1) : 0);
+            p = (unsigned)(min(y, H - 1) * W) + l_xsc;
+            lo = (row_live && lactive) ? (slot_mod(br) * YP + yp) * ROWB + l_rec : kLdsDump;
+        };
         TA_ a_even, a_odd;                              // stage A of the pixels with even / odd index
         TA_ ab; TB_ bb; SvgfReproj rb;                  // the pixel between stages B and C1
         TA_ ac; TC_ cc;                                 // the pixel between stages C1 and C2
@@ -703,13 +756,13 @@ __global__ __launch_bounds__(NT) void k_atrous_lane(AtrousArgs a, LaneGeom gm, s
             if (!PRO && !(u & 1)) stamp(0);
             if (!PRO || u >= 4) {                               // C2: blend, ring record + planes
                 int lo, fl; unsigned p;
-                describe_px(u - 4, lo, p, fl);
+                if constexpr (PRO) describe_px(u - 4, lo, p, fl); else describe_loop_px(u - 4, lo, p, fl);
                 t_stage_c2(ac, cc, fl, p, lo);
             }
             if (!PRO && !(u & 1)) stamp(1);
             if (!PRO || (u >= 3 && (u - 3 < 4 || is_loader))) { // C1: consistency, history request
                 int lo, fl; unsigned p;
-                describe_px(u - 3, lo, p, fl);
+                if constexpr (PRO) describe_px(u - 3, lo, p, fl); else describe_loop_px(u - 3, lo, p, fl);
                 ac = ab;
                 t_stage_c1(ac, bb, rb, fl, p, cc);
             }
@@ -721,7 +774,7 @@ __global__ __launch_bounds__(NT) void k_atrous_lane(AtrousArgs a, LaneGeom gm, s
             if (!PRO && !(u & 1)) stamp(3);
             if (!PRO || u < 4 || is_loader) {                   // A: primary loads
                 int lo, fl; unsigned p;
-                describe_px(u, lo, p, fl);
+                if constexpr (PRO) describe_px(u, lo, p, fl); else describe_loop_px(u, lo, p, fl);
                 t_stage_a(abuf, p);
             }
             if (!PRO && !(u & 1)) stamp(4);
@@ -1335,7 +1388,7 @@ inline long lane_segment_search(int n_strips, int S, int nb_max, int n_cu, int *
 }
 
 template <int LOG2S, bool HASVAR, int LOG2P = LOG2S, int LOG2Y = 0, int FUSED = 0, int REUSE = 0>
-hipError_t launch_lane_cfg(const AtrousArgs &a, hipStream_t s, const TemporalArgs *ta = nullptr)
+hipError_t launch_lane_cfg(const AtrousArgs &a, hipStream_t s, const LaneFused *ta = nullptr)
 {
     constexpr int S = 1 << LOG2S, P = 1 << LOG2P, YP = 1 << LOG2Y, M = LOUT * (NWC / (P * YP)) + 4, MP = (P == 4) ? M + 2 : ((M * 12 % 64 == 0) ? M + 1 : M), BM = (BW + S - 1) / S;
     constexpr size_t kLds = (size_t)R * YP * P * MP * PXB + (size_t)2 * (YP > 1 ? 0 : (P < S ? P * M : 2 * S * BM)) * 4 + 16 + (FUSED != 0 ? 80 : 0);

@@ -94,6 +94,8 @@ struct TemporalArgs {
     const float *pos_prev;    // previous frame's positions (packed float3), read only when pos_tol > 0
     float pos_tol;            // SvgfParams::reproj_position_tol; 0 = the reference's consistency test
     void *dump;               // fused kernel only: >= 4 KB of scrap the stores of pixels a workgroup does not own go to
+    const void *arena;        // fused kernel only: the ONE allocation all the context's planes (and dump) live in, and its size:
+    size_t arena_bytes;       // the kernel addresses them as arena + 32-bit offset (svgf_atrous_lane_impl.h: LaneFused)
 };
 
 hipError_t launch_temporal(const TemporalArgs &a, hipStream_t s, bool single_wave_blocks);

@@ -32,6 +32,7 @@ def main():
     ap.add_argument("--blur", type=int, default=1, help="SvgfParams.blur_variance")
     ap.add_argument("--reps", type=int, default=20, help="frames of the back-to-back wall-time loop (no per-kernel events)")
     ap.add_argument("--planar", action="store_true", help="G-buffer handed over as planes (svgf_denoise_planar), static scene")
+    ap.add_argument("--telemetry-json", default=None, help="append one JSON line per variant: {variant, frame_us, telemetry summary} (the A/B scripts' clock check)")
     a = ap.parse_args()
     import torch
     pkg = ge.load_package()
@@ -84,6 +85,10 @@ def main():
         med = [float(np.median([r[k][1] for r in steady])) for k in range(nk)]
         kinds = [steady[0][k][0] for k in range(nk)]
         print(f"variant {v}: frame wall {frame_ms*1e3:.1f} us = {n/frame_ms/1e3:.1f} Mpix/s ({reps} frames back to back); sum of kernels {sum(med)*1e3:.1f} us")
+        if a.telemetry_json:
+            import json
+            with open(a.telemetry_json, "a") as fh:
+                fh.write(json.dumps({"variant": v, "frame_us": frame_ms * 1e3, "telemetry": tms}) + "\n")
         print(f"   telemetry during the wall-time loop: sclk {tms['sclk_mhz']} MHz, power {tms['power_w']} W, temp {tms['temp_c']} C ({tms['n']} samples, {tms['source']})")
         lvl = 0
         for k in range(nk):
