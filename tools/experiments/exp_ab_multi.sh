@@ -32,11 +32,13 @@ for t in tags:
     except OSError:
         rows = []
     clk = [r["telemetry"]["sclk_mhz"]["median"] for r in rows if r["telemetry"].get("sclk_mhz") and r["telemetry"]["sclk_mhz"].get("median")]
-    summ[t] = {"sclk_mhz": {"median": statistics.median(clk)} if clk else None, "runs": len(rows), "frame_us": [round(r["frame_us"], 1) for r in rows]}
-    print(f"clock {t}: median sclk {summ[t]['sclk_mhz']['median'] if clk else None} MHz over {len(rows)} runs; frame wall {summ[t]['frame_us']} us")
+    pw = [r["telemetry"]["power_w"]["median"] for r in rows if r["telemetry"].get("power_w") and r["telemetry"]["power_w"].get("median")]
+    summ[t] = {"sclk_mhz": {"median": statistics.median(clk)} if clk else None, "power_w": {"median": statistics.median(pw)} if pw else None,
+               "runs": len(rows), "frame_us": [round(r["frame_us"], 1) for r in rows]}
+    print(f"clock {t}: median sclk {summ[t]['sclk_mhz']['median'] if clk else None} MHz, power {summ[t]['power_w']['median'] if pw else None} W over {len(rows)} runs; frame wall {summ[t]['frame_us']} us")
 for i in range(len(tags)):
     for j in range(i + 1, len(tags)):
         ok = telemetry.comparable(summ[tags[i]], summ[tags[j]], tol=0.02)
-        print(f"{tags[i]} vs {tags[j]}: " + ("comparable (sclk within 2 %)" if ok else "REFUSED: shader clocks differ by more than 2 % (or were not sampled) -- not an A/B"))
+        print(f"{tags[i]} vs {tags[j]}: " + ("comparable (sclk within 2 %, power within 10 %)" if ok else "REFUSED: shader clocks differ by more than 2 % or socket power by more than 10 % (or were not sampled) -- not an A/B"))
 PY
 rm -f /tmp/ab_tm_*.jsonl

@@ -148,13 +148,22 @@ class Sampler:
         return {"source": self.source, "n": len(rows), "sclk_mhz": stat(1), "power_w": stat(2), "temp_c": stat(3)}
 
 
-def comparable(a: dict, b: dict, tol: float = 0.02) -> bool:
-    """True when two telemetry summaries ran at the same shader clock (median within `tol`)."""
+def comparable(a: dict, b: dict, tol: float = 0.02, power_tol: float = 0.10) -> bool:
+    """True when two telemetry summaries ran in the same clock state: median shader clock within `tol` AND — when both carry
+    power samples — median socket power within `power_tol`.  The power test is not a luxury: after 20 ms of idle time the
+    reported sclk of an MI355X is back at 2.39 GHz at once while the socket power (and the frame rate: -18 %) takes tens of
+    frames to return to the sustained figure (profiles/r04_clock_states.txt)."""
     try:
         fa, fb = a["sclk_mhz"]["median"], b["sclk_mhz"]["median"]
     except (KeyError, TypeError):
         return False
-    return abs(fa - fb) <= tol * max(fa, fb)
+    if abs(fa - fb) > tol * max(fa, fb):
+        return False
+    try:
+        pa, pb = a["power_w"]["median"], b["power_w"]["median"]
+    except (KeyError, TypeError):
+        return True
+    return abs(pa - pb) <= power_tol * max(pa, pb)
 
 
 if __name__ == "__main__":
