@@ -1,3 +1,4 @@
+# (round 4: every run holds the sustained clock state, probe.py --sustain 0.6; the kernel averages are over ~7 000 sustained launches)
 # A/B/C/... of prebuilt libraries (libsvgf_hip.so.A, .B, ... next to the real one), alternating on one box; rocprofv3 kernel averages.
 # usage: exp_ab_multi.sh "A B C" [kernel_variant] [rounds]
 cd /tmp && export TMPDIR=/tmp
@@ -7,7 +8,7 @@ L=$R/cuda-path-tracer-denoising_amd/libsvgf_hip.so
 cp $L $L.orig
 for i in $(seq 1 ${3:-3}); do for v in $1; do
   cp $L.$v $L; touch $L
-  rocprofv3 --kernel-trace --stats -d $R/gpurun_out/ab_prof -o p --output-format csv -- python $R/tools/probe.py --variants ${2:-0} --frames 24 --reps 200 --telemetry-json /tmp/ab_tm_$v.jsonl > /dev/null 2>&1
+  rocprofv3 --kernel-trace --stats -d $R/gpurun_out/ab_prof -o p --output-format csv -- python $R/tools/probe.py --variants ${2:-0} --frames 24 --reps 200 --sustain 0.6 --telemetry-json /tmp/ab_tm_$v.jsonl > /dev/null 2>&1
   python - "$v" <<PY
 import csv,glob,sys
 f=glob.glob("$R/gpurun_out/ab_prof/**/*kernel_stats.csv", recursive=True)[0]

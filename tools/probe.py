@@ -32,6 +32,8 @@ def main():
     ap.add_argument("--blur", type=int, default=1, help="SvgfParams.blur_variance")
     ap.add_argument("--reps", type=int, default=20, help="frames of the back-to-back wall-time loop (no per-kernel events)")
     ap.add_argument("--planar", action="store_true", help="G-buffer handed over as planes (svgf_denoise_planar), static scene")
+    ap.add_argument("--sustain", type=float, default=0.0, help="seconds of back-to-back frames in front of every measurement (the sustained clock / "
+                    "power state bench.py measures in, DESIGN.md 6.2); 0 = measure from wherever the GPU is (cold after start-up)")
     ap.add_argument("--telemetry-json", default=None, help="append one JSON line per variant: {variant, frame_us, telemetry summary} (the A/B scripts' clock check)")
     a = ap.parse_args()
     import torch
@@ -55,7 +57,20 @@ def main():
                 d.denoise_planar(out, d_in[0], cam[0], p)
             torch.cuda.synchronize()
             d.denoise = lambda o, i, g, c, pp, _d=d: _d.denoise_planar(o, i, c, pp)
+        def sustain():
+            if a.sustain <= 0:
+                return
+            import time
+            t, k = time.perf_counter(), 0
+            while time.perf_counter() - t < a.sustain:
+                d.denoise(out, d_in[k % nsrc], d_g[k % nsrc], cam[k % nsrc], p)
+                k += 1
+                if k % 32 == 0:
+                    torch.cuda.synchronize()
+            torch.cuda.synchronize()
         d.profile_enable(a.frames)
+        sustain()
+        d.profile_enable(a.frames)        # (same slot count: only the counters restart, no idle time)
         outs = []
         for f in range(a.frames):
             d.denoise(out, d_in[f % nsrc], d_g[f % nsrc], cam[f % nsrc], p)
@@ -66,6 +81,7 @@ def main():
         # whole-frame wall time without per-kernel events
         d.profile_enable(0)
         torch.cuda.synchronize()
+        sustain()
         e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
         reps = a.reps
         with telemetry.Sampler(0) as tm:
@@ -75,6 +91,8 @@ def main():
             e1.record(); torch.cuda.synchronize()
         frame_ms = e0.elapsed_time(e1) / reps
         tms = tm.summary()
+        d.profile_enable(a.frames)
+        sustain()
         d.profile_enable(a.frames)
         for f in range(a.frames):
             d.denoise(out, d_in[f % nsrc], d_g[f % nsrc], cam[f % nsrc], p)
