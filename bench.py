@@ -13,7 +13,8 @@ Rank 0 prints ONE JSON line.  `value` is the pipelined throughput (K calls enque
 the end); `latency_ms_sync` is the metric as SURVEY.md §8(d)(i) words it — the median wall time of one svgf_denoise +
 svgf_sync pair, what the reference's synchronous denoise() (src/denoise.cu:401) gives its caller.  `roofline` is for the
 dominant kernel (the a-trous level): algorithmic bytes per launch (56 B/pixel) / mean launch duration from
-HIP events recorded on the launch stream inside the timed region.  `telemetry` holds shader clock / power / temperature
+HIP events attached to the kernel dispatches of the launch stream inside the timed region (hipExtLaunchKernelGGL: the kernel's
+own begin / end timestamps; they agree with rocprofv3's durations of the same command to 2 %, profiles/).  `telemetry` holds shader clock / power / temperature
 sampled while each of the three measurements ran (tools/telemetry.py).  `cpu_baseline` (N == 1 only) times the CPU oracle —
 a port, not the product — on the host cores.
 """
@@ -256,7 +257,7 @@ def main():
     out = torch.empty((H, W, 3), dtype=torch.float32, device=dev)
     den = pkg.Denoiser(W, H, device=local_rank)
     stream = torch.cuda.current_stream(dev)
-    PROFILE_STRIDE = 8      # HIP-event pairs around every kernel of every 8th timed step (they widen the launch gaps)
+    PROFILE_STRIDE = 8      # an event pair attached to every kernel dispatch of every 8th timed step (a timed frame runs ~25 us longer)
     den.profile_stride(PROFILE_STRIDE)
     den.profile_enable(a.steps)
 
@@ -299,7 +300,7 @@ def main():
     dt, pixels = pkg.farm.timed_region(step, a.steps, 0, lambda: torch.cuda.synchronize(dev), dist=dist, device=None if share_device else dev)
     t_region1 = time.perf_counter()
 
-    # per-kernel durations of the timed steps (HIP events on the launch stream)
+    # per-kernel durations of the timed steps (HIP events attached to the dispatches on the launch stream)
     atrous_ms, temporal_ms, fused_ms = [], [], []
     for s in range(min(a.steps, den.profile_frames())):
         for kind, ms in den.profile_read(s):
@@ -392,7 +393,7 @@ def main():
                          "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, profiles/pmc_traffic.json (FETCH x2 per MI355X_MICROARCH.md)",
                          "kernel": "one plain a-trous level: k_atrous_lane (steps 4-32 when the first level is fused with the temporal pass, else 2-32; k_atrous_strip where the library's cost model prefers it); mean over those launches of a frame; the fused temporal + first-level launch is reported under kernels_us", "bytes_per_launch": ATROUS_BYTES_PER_PIXEL * W * H,
                          "mean_launch_us": round(a_ms * 1e3, 2), "launches_timed": len(atrous_ms),
-                         "note": "everything ordered on one stream; 'isolated' repeats the measurement with events around every kernel of 16 frames",
+                         "note": "everything ordered on one stream; durations are the dispatches' own begin / end timestamps (HIP events attached by hipExtLaunchKernelGGL on the launch stream, every 8th timed frame); 'isolated' repeats the measurement on every kernel of 16 frames",
                          "isolated": {"mean_launch_us": round(iso_us, 2), "achieved": round(iso_gbs, 1),
                                       "frac": round(iso_gbs / HBM_PEAK_GBS, 4), "launches_timed": len(iso_atrous_ms)},
                          # the secondary limiter.  24 taps x (2 v_sqrt + 1 v_exp) + 5 (centre, normalisation) per pixel-level

@@ -61,7 +61,6 @@ struct svgf_ctx {
     hipEvent_t *ev;        // prof_frames * SVGF_MAX_KERNELS_PER_FRAME * 2
     int *ev_kind;          // prof_frames * SVGF_MAX_KERNELS_PER_FRAME
     int *ev_n;             // prof_frames
-    int *ev_begin;         // prof_frames * SVGF_MAX_KERNELS_PER_FRAME: index (within the frame's events) of the event in front of a launch
     char err[512];
 };
 
@@ -156,7 +155,7 @@ static void free_all(svgf_ctx *c)
     if (c->st_g) (void)hipFree(c->st_g);
     if (c->ev) {
         for (long long k = 0; k < (long long)c->prof_frames * SVGF_MAX_KERNELS_PER_FRAME * 2; k++) (void)hipEventDestroy(c->ev[k]);
-        free(c->ev); free(c->ev_kind); free(c->ev_n); free(c->ev_begin);
+        free(c->ev); free(c->ev_kind); free(c->ev_n);
     }
 }
 
@@ -306,8 +305,8 @@ extern "C" int svgf_profile_enable(svgf_ctx *c, int nframes)
     }
     if (c->ev) {
         for (long long k = 0; k < (long long)c->prof_frames * SVGF_MAX_KERNELS_PER_FRAME * 2; k++) (void)hipEventDestroy(c->ev[k]);
-        free(c->ev); free(c->ev_kind); free(c->ev_n); free(c->ev_begin);
-        c->ev = nullptr; c->ev_kind = nullptr; c->ev_n = nullptr; c->ev_begin = nullptr;
+        free(c->ev); free(c->ev_kind); free(c->ev_n);
+        c->ev = nullptr; c->ev_kind = nullptr; c->ev_n = nullptr;
     }
     c->prof_frames = 0; c->prof_count = 0; c->frame_no = 0;
     if (c->prof_stride < 1) c->prof_stride = 1;
@@ -316,18 +315,17 @@ extern "C" int svgf_profile_enable(svgf_ctx *c, int nframes)
     c->ev = (hipEvent_t *)calloc(ne, sizeof(hipEvent_t));
     c->ev_kind = (int *)calloc((size_t)nframes * SVGF_MAX_KERNELS_PER_FRAME, sizeof(int));
     c->ev_n = (int *)calloc(nframes, sizeof(int));
-    c->ev_begin = (int *)calloc((size_t)nframes * SVGF_MAX_KERNELS_PER_FRAME, sizeof(int));
-    if (!c->ev || !c->ev_kind || !c->ev_n || !c->ev_begin) {
-        free(c->ev); free(c->ev_kind); free(c->ev_n); free(c->ev_begin);
-        c->ev = nullptr; c->ev_kind = nullptr; c->ev_n = nullptr; c->ev_begin = nullptr;
+    if (!c->ev || !c->ev_kind || !c->ev_n) {
+        free(c->ev); free(c->ev_kind); free(c->ev_n);
+        c->ev = nullptr; c->ev_kind = nullptr; c->ev_n = nullptr;
         return SVGF_ERR_OOM;
     }
     for (long long k = 0; k < ne; k++) {
         hipError_t e = hipEventCreate(&c->ev[k]);
         if (e != hipSuccess) {          // give back what was created: profiling stays off
             for (long long j = 0; j < k; j++) (void)hipEventDestroy(c->ev[j]);
-            free(c->ev); free(c->ev_kind); free(c->ev_n); free(c->ev_begin);
-            c->ev = nullptr; c->ev_kind = nullptr; c->ev_n = nullptr; c->ev_begin = nullptr;
+            free(c->ev); free(c->ev_kind); free(c->ev_n);
+            c->ev = nullptr; c->ev_kind = nullptr; c->ev_n = nullptr;
             snprintf(c->err, sizeof(c->err), "svgf_profile_enable: hipEventCreate failed: %s", hipGetErrorString(e));
             return SVGF_ERR_HIP;
         }
@@ -355,7 +353,7 @@ extern "C" int svgf_profile_read(svgf_ctx *c, int slot, int max_entries, int *ki
     for (int k = 0; k < nk && w < max_entries; k++, w++) {
         const long long base = ((long long)slot * SVGF_MAX_KERNELS_PER_FRAME + k) * 2;
         float t = 0.0f;
-        HIPC(c, hipEventElapsedTime(&t, c->ev[(long long)slot * SVGF_MAX_KERNELS_PER_FRAME * 2 + c->ev_begin[slot * SVGF_MAX_KERNELS_PER_FRAME + k]], c->ev[base + 1]));
+        HIPC(c, hipEventElapsedTime(&t, c->ev[base], c->ev[base + 1]));
         if (kinds) kinds[w] = c->ev_kind[slot * SVGF_MAX_KERNELS_PER_FRAME + k];
         if (ms) ms[w] = t;
     }
@@ -364,38 +362,40 @@ extern "C" int svgf_profile_read(svgf_ctx *c, int slot, int max_entries, int *ki
 }
 
 namespace {
-// Brackets one launch with events when profiling is on.  A frame's launches follow one another on one stream, so the event
-// behind launch k is also the event in front of launch k + 1: one record per launch plus one per frame instead of two per
-// launch.  Every record costs the stream ~4 us (a barrier packet between two kernels that would otherwise follow each other
-// without a gap: profiles/r04_clock_states.txt, 12 records = +46 us per 1080p frame), which is time the instrumented frames
-// of bench.py's timed region add to its whole-job figure.  `chained` is false after anything else was enqueued in between.
+// Times one launch when profiling is on: the event pair of the slot is armed for the next kernel launch of this thread and
+// the launcher's SVGF_LAUNCH_KERNEL attaches it to the dispatch (svgf_kernels.h).  Nothing is recorded on the stream.
 struct KernelTimer {
-    svgf_ctx *c; hipStream_t s; int slot; int k; bool on; bool chained;
+    svgf_ctx *c; hipStream_t s; int slot; int k; bool on;
     bool begin(int kind) {
         if (!on) return true;
         k = c->ev_n[slot];
         if (k >= SVGF_MAX_KERNELS_PER_FRAME) return true;
-        const int e = slot * SVGF_MAX_KERNELS_PER_FRAME + k;
+        const long long e = (long long)slot * SVGF_MAX_KERNELS_PER_FRAME + k;
         c->ev_kind[e] = kind;
-        if (chained && k > 0) { c->ev_begin[e] = (k - 1) * 2 + 1; return true; }       // the previous launch's end event
-        c->ev_begin[e] = k * 2;
-        return hipEventRecord(c->ev[(long long)e * 2], s) == hipSuccess;
+        g_svgf_launch_events = SvgfLaunchEvents{ c->ev[e * 2], c->ev[e * 2 + 1] };
+        return true;
     }
     bool end() {
         if (!on || k >= SVGF_MAX_KERNELS_PER_FRAME) return true;
-        c->ev_n[slot] = k + 1;
-        chained = true;
-        return hipEventRecord(c->ev[((long long)slot * SVGF_MAX_KERNELS_PER_FRAME + k) * 2 + 1], s) == hipSuccess;
+        const bool consumed = (g_svgf_launch_events.start == nullptr);      // a launcher that did not go through the macro: no entry
+        g_svgf_launch_events = SvgfLaunchEvents{ nullptr, nullptr };
+        if (consumed) c->ev_n[slot] = k + 1;
+        return true;
     }
-    void other_work_enqueued() { chained = false; }
 };
 }  // namespace
 
+thread_local SvgfLaunchEvents g_svgf_launch_events = { nullptr, nullptr };
+
 #define LAUNCH(kind, expr)                                                                           \
     do {                                                                                             \
-        if (!timer.begin(kind)) { snprintf(c->err, sizeof(c->err), "hipEventRecord failed"); return SVGF_ERR_HIP; } \
-        HIPC(c, (expr));                                                                             \
-        if (!timer.end()) { snprintf(c->err, sizeof(c->err), "hipEventRecord failed"); return SVGF_ERR_HIP; }       \
+        timer.begin(kind);                                                                           \
+        const hipError_t le__ = (expr);                                                              \
+        timer.end();          /* (also disarms the event pair when the launcher failed before launching) */ \
+        if (le__ != hipSuccess) {                                                                    \
+            snprintf(c->err, sizeof(c->err), "%s failed: %s (%s:%d)", #expr, hipGetErrorString(le__), __FILE__, __LINE__); \
+            return SVGF_ERR_HIP;                                                                     \
+        }                                                                                            \
     } while (0)
 
 // ---- the frame ------------------------------------------------------------------------------------------------
@@ -472,7 +472,7 @@ static int denoise_frame(svgf_ctx *c, void *out_rgb_dev, const void *in_rgb_dev,
     const float *g = (const float *)gbuffer_dev;
     const int n = (int)c->n;
 
-    KernelTimer timer{ c, s, 0, 0, false, false };
+    KernelTimer timer{ c, s, 0, 0, false };
     if (c->prof_frames && (c->frame_no % (c->prof_stride > 0 ? c->prof_stride : 1)) == 0) {
         timer.on = true;
         timer.slot = (int)(c->prof_count % c->prof_frames);
@@ -521,7 +521,7 @@ static int denoise_frame(svgf_ctx *c, void *out_rgb_dev, const void *in_rgb_dev,
     c->vp_valid &= ~(1u << acc);     // the temporal / prepare pass writes no variance plane: the first level gathers cv.w
     c->acc = acc;
     c->hist = acc;                                   // color_history <- color_acc / input (:366,370)
-    if (c->capture && !fused) { HIPC(c, hipMemcpyAsync(c->cv_capture, c->cv[acc], c->n * sizeof(float4), hipMemcpyDeviceToDevice, s)); timer.other_work_enqueued(); }
+    if (c->capture && !fused) { HIPC(c, hipMemcpyAsync(c->cv_capture, c->cv[acc], c->n * sizeof(float4), hipMemcpyDeviceToDevice, s)); }
 
     // 2) debug views, pass-through or the a-trous cascade (:373-394)
     if (p->right_view_option == 1) {
@@ -605,7 +605,7 @@ static int denoise_frame(svgf_ctx *c, void *out_rgb_dev, const void *in_rgb_dev,
                 // history is not this level's output) or a test (svgf_set_capture)
                 t.cv_acc = (!keep || c->capture) ? c->cv[acc] : nullptr;
                 LAUNCH(SVGF_KERNEL_FUSED, launch_atrous_fused(a, t, s));
-                if (c->capture) { HIPC(c, hipMemcpyAsync(c->cv_capture, c->cv[acc], c->n * sizeof(float4), hipMemcpyDeviceToDevice, s)); timer.other_work_enqueued(); }
+                if (c->capture) { HIPC(c, hipMemcpyAsync(c->cv_capture, c->cv[acc], c->n * sizeof(float4), hipMemcpyDeviceToDevice, s)); }
                 break;
             case K_LANE:    LAUNCH(SVGF_KERNEL_ATROUS, launch_atrous_lane(a, s)); break;     // steps 2 .. 32: symmetric terms evaluated once
             case K_LANE2Y:  LAUNCH(SVGF_KERNEL_ATROUS, launch_atrous_lane_2y(a, s)); break;  // A/B partner of the fused kernel's geometry

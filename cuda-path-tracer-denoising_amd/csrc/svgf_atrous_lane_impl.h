@@ -1422,8 +1422,8 @@ hipError_t launch_lane_cfg(const AtrousArgs &a, hipStream_t s, const LaneFused *
         gm.dbg = dbg_buf; gm.dbg_block = atoi(dbg_env);
     }
 #endif
-    if constexpr (FUSED != 0) hipLaunchKernelGGL((k_atrous_lane<LOG2S, HASVAR, LOG2P, LOG2Y, FUSED, REUSE>), dim3(nblocks), dim3(NT), lds, s, a, gm, *ta);
-    else hipLaunchKernelGGL((k_atrous_lane<LOG2S, HASVAR, LOG2P, LOG2Y, 0, REUSE>), dim3(nblocks), dim3(NT), lds, s, a, gm, LaneNoTemporal{});
+    if constexpr (FUSED != 0) SVGF_LAUNCH_KERNEL((k_atrous_lane<LOG2S, HASVAR, LOG2P, LOG2Y, FUSED, REUSE>), dim3(nblocks), dim3(NT), lds, s, a, gm, *ta);
+    else SVGF_LAUNCH_KERNEL((k_atrous_lane<LOG2S, HASVAR, LOG2P, LOG2Y, 0, REUSE>), dim3(nblocks), dim3(NT), lds, s, a, gm, LaneNoTemporal{});
 #ifdef SVGF_LANE_TIMELINE
     if (dbg_env) {
         static int skip = getenv("SVGF_LANE_DBG_SKIP") ? atoi(getenv("SVGF_LANE_DBG_SKIP")) : 0, prints = 0;

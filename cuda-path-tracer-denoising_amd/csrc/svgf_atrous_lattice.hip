@@ -264,7 +264,7 @@ hipError_t launch_cfg(const AtrousArgs &a, const LatticeGeom &gm, hipStream_t s)
     if (hipError_t e = cache.init(reinterpret_cast<const void *>(&k_atrous_lattice<HASVAR>), kLdsBudget, &dev_id); e != hipSuccess) return e;
     const size_t lds = (size_t)(gm.pstride << gm.log2k) * (gm.band_rows + 4) * PXB;
     const unsigned nblocks = (((unsigned)a.step * (unsigned)a.step) >> gm.log2k) * (unsigned)gm.n_bands;
-    hipLaunchKernelGGL(k_atrous_lattice<HASVAR>, dim3(nblocks), dim3(NT), lds, s, a, gm);
+    SVGF_LAUNCH_KERNEL(k_atrous_lattice<HASVAR>, dim3(nblocks), dim3(NT), lds, s, a, gm);
     return hipGetLastError();
 }
 

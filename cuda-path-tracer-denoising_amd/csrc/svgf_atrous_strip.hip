@@ -707,7 +707,7 @@ hipError_t launch_cfg(const AtrousArgs &a, hipStream_t s)
     gm.kx = (float)(1.4426950408889634 / ((double)a.sigma_x + 1e-6));
     const int groups_pad = (gm.n_groups + 7) / 8 * 8;
     const int nblocks = groups_pad * gm.n_strips;
-    hipLaunchKernelGGL((k_atrous_strip<LOG2S, TX, ROWS, HASVAR>), dim3(nblocks), dim3(TX * ROWS + kLoaderThreads), lds, s, a, gm);
+    SVGF_LAUNCH_KERNEL((k_atrous_strip<LOG2S, TX, ROWS, HASVAR>), dim3(nblocks), dim3(TX * ROWS + kLoaderThreads), lds, s, a, gm);
     if (dbg_env) {
         static int prints = 0;
         (void)hipStreamSynchronize(s);

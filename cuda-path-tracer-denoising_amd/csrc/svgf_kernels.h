@@ -12,7 +12,26 @@
 // frame, by the temporal (or prepare) kernel, which splits it into the NRM/POS/GID planes the a-trous levels read.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <mutex>
+
+// Profiling hand-off.  svgf_api.hip's KernelTimer arms an event pair for the NEXT kernel launch of this host thread; the launch
+// macro hands it to hipExtLaunchKernelGGL, which attaches the events to the DISPATCH itself: start / stop are the kernel's own
+// begin / end timestamps (what rocprofv3 reports), and nothing is added to the stream.  hipEventRecord pairs around a launch —
+// rounds 1-3 — put a barrier packet on either side of every kernel: the intervals read 2-3 us long and an instrumented frame
+// ran 23-46 us longer (profiles/r04_clock_states.txt).
+struct SvgfLaunchEvents { hipEvent_t start, stop; };
+extern thread_local SvgfLaunchEvents g_svgf_launch_events;      // defined in svgf_api.hip
+#define SVGF_LAUNCH_KERNEL(kernel, grid, block, lds, stream, ...)                                                        \
+    do {                                                                                                                 \
+        if (g_svgf_launch_events.start) {                                                                                \
+            const SvgfLaunchEvents ev__ = g_svgf_launch_events;                                                          \
+            g_svgf_launch_events = SvgfLaunchEvents{ nullptr, nullptr };                                                 \
+            hipExtLaunchKernelGGL(kernel, grid, block, lds, stream, ev__.start, ev__.stop, 0, __VA_ARGS__);              \
+        } else {                                                                                                         \
+            hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__);                                           \
+        }                                                                                                                \
+    } while (0)
 
 // Per-device launch state of ONE kernel instantiation (a function-local static of its launcher).  The opt-in to more than
 // 64 KB of dynamic LDS is a per-device function attribute and the CU count a device property; the ABI allows one context

@@ -130,8 +130,8 @@ hipError_t launch_temporal(const TemporalArgs &a, hipStream_t s, bool single_wav
     const long long n = (long long)a.W * a.H;
     // When this pass runs beside an a-trous launch (cross-frame overlap) only single free wave slots exist on a CU:
     // one-wave workgroups can be placed in them, four-wave workgroups cannot.
-    if (single_wave_blocks) hipLaunchKernelGGL(k_temporal<64>, dim3(div_up(n, 64)), dim3(64), 0, s, a);
-    else hipLaunchKernelGGL(k_temporal<SVGF_BLOCK>, dim3(div_up(n, SVGF_BLOCK)), dim3(SVGF_BLOCK), 0, s, a);
+    if (single_wave_blocks) SVGF_LAUNCH_KERNEL(k_temporal<64>, dim3(div_up(n, 64)), dim3(64), 0, s, a);
+    else SVGF_LAUNCH_KERNEL(k_temporal<SVGF_BLOCK>, dim3(div_up(n, SVGF_BLOCK)), dim3(SVGF_BLOCK), 0, s, a);
     return hipGetLastError();
 }
 
@@ -177,7 +177,7 @@ __global__ __launch_bounds__(SVGF_BLOCK) void k_spatial_variance(float4 *__restr
 hipError_t launch_spatial_variance(float4 *cv_acc, const float2 *mom_acc, const int *hlen_upd, const float *nrm, const int *gid,
                                    int W, int H, int K, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_spatial_variance, dim3((W + 63) / 64, (H + SVGF_BLOCK / 64 - 1) / (SVGF_BLOCK / 64)), dim3(SVGF_BLOCK), 0, s,
+    SVGF_LAUNCH_KERNEL(k_spatial_variance, dim3((W + 63) / 64, (H + SVGF_BLOCK / 64 - 1) / (SVGF_BLOCK / 64)), dim3(SVGF_BLOCK), 0, s,
                        cv_acc, mom_acc, hlen_upd, nrm, gid, W, H, K);
     return hipGetLastError();
 }
@@ -205,7 +205,7 @@ hipError_t launch_prepare(const float *in_rgb, const float *gbuf, float4 *cv, fl
                           int W, int H, hipStream_t s)
 {
     const long long n = (long long)W * H;
-    hipLaunchKernelGGL(k_prepare, dim3(div_up(n, SVGF_BLOCK)), dim3(SVGF_BLOCK), 0, s, in_rgb, gbuf, cv, nrm, gid, pos, (int)n);
+    SVGF_LAUNCH_KERNEL(k_prepare, dim3(div_up(n, SVGF_BLOCK)), dim3(SVGF_BLOCK), 0, s, in_rgb, gbuf, cv, nrm, gid, pos, (int)n);
     return hipGetLastError();
 }
 
@@ -287,7 +287,7 @@ __global__ __launch_bounds__(SVGF_BLOCK) void k_atrous_gather(AtrousArgs a)
 hipError_t launch_atrous_gather(const AtrousArgs &a, hipStream_t s)
 {
     const long long n = (long long)a.W * a.H;
-    hipLaunchKernelGGL(k_atrous_gather, dim3(div_up(n, SVGF_BLOCK)), dim3(SVGF_BLOCK), 0, s, a);
+    SVGF_LAUNCH_KERNEL(k_atrous_gather, dim3(div_up(n, SVGF_BLOCK)), dim3(SVGF_BLOCK), 0, s, a);
     return hipGetLastError();
 }
 
@@ -319,16 +319,16 @@ __global__ __launch_bounds__(SVGF_BLOCK) void k_copy_rgb(const float4 *__restric
 
 hipError_t launch_debug_hlen(const int *hlen, float *out_rgb, int n, float scale, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_debug_hlen, dim3(div_up(n, SVGF_BLOCK)), dim3(SVGF_BLOCK), 0, s, hlen, out_rgb, n, scale);
+    SVGF_LAUNCH_KERNEL(k_debug_hlen, dim3(div_up(n, SVGF_BLOCK)), dim3(SVGF_BLOCK), 0, s, hlen, out_rgb, n, scale);
     return hipGetLastError();
 }
 hipError_t launch_debug_var(const float4 *cv, float *out_rgb, int n, float scale, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_debug_var, dim3(div_up(n, SVGF_BLOCK)), dim3(SVGF_BLOCK), 0, s, cv, out_rgb, n, scale);
+    SVGF_LAUNCH_KERNEL(k_debug_var, dim3(div_up(n, SVGF_BLOCK)), dim3(SVGF_BLOCK), 0, s, cv, out_rgb, n, scale);
     return hipGetLastError();
 }
 hipError_t launch_copy_rgb(const float4 *cv, float *out_rgb, int n, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_copy_rgb, dim3(div_up(n, SVGF_BLOCK)), dim3(SVGF_BLOCK), 0, s, cv, out_rgb, n);
+    SVGF_LAUNCH_KERNEL(k_copy_rgb, dim3(div_up(n, SVGF_BLOCK)), dim3(SVGF_BLOCK), 0, s, cv, out_rgb, n);
     return hipGetLastError();
 }

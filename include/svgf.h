@@ -189,8 +189,10 @@ int svgf_set_capture(svgf_ctx *ctx, int on);
 #define SVGF_KERNEL_DEBUGVIEW  4
 #define SVGF_KERNEL_COPYOUT    5
 #define SVGF_KERNEL_FUSED      6   /* temporal pass + first a-trous level in one launch (ABI 0.6) */
-/* svgf_profile_stride(ctx, k): bracket only every k-th frame (k >= 1, default 1); the event records lengthen the gaps
- * between kernels by a few microseconds, so a throughput run samples a subset of its frames. */
+/* Timing source: an event pair attached to each kernel dispatch (hipExtLaunchKernelGGL): the kernel's own begin / end
+ * timestamps, nothing recorded on the stream.
+ * svgf_profile_stride(ctx, k): time only every k-th frame (k >= 1, default 1).
+ * svgf_profile_enable(ctx, n) with the n already armed restarts the counters without re-creating events. */
 int svgf_profile_enable(svgf_ctx *ctx, int nframes);
 int svgf_profile_stride(svgf_ctx *ctx, int every_kth_frame);
 long long svgf_profile_frames(const svgf_ctx *ctx);
