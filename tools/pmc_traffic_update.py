@@ -28,7 +28,7 @@ d["why_above_algorithmic"] = ("4 halo rows per 17-row segment (x1.24 on the 40 B
                               "or three XCDs that hold neighbouring y-phases) instead of ~24 B/px of 4-byte gathers from 16-byte texels")
 d["_comment"] = ("HBM-side traffic of the a-trous kernels (default path at 1920 columns: k_atrous_lane on all five levels) from rocprofv3 "
                  "PMC, collected as MI355X_MICROARCH.md prescribes: FETCH_SIZE and WRITE_SIZE in separate --pmc passes "
-                 "(profiles/r03_pmc_hbm.txt), KiB units, FETCH_SIZE doubled (gfx950 tallies 128-B read requests at 64 B). "
+                 "(profiles/r04_pmc_hbm.txt), KiB units, FETCH_SIZE doubled (gfx950 tallies 128-B read requests at 64 B). "
                  "Bytes per pixel per launch, 1920x1080.  Reported by bench.py only while kernel_sources_sha16 matches the sources.")
 json.dump(d, open(p, "w"), indent=2)
 print(json.dumps(lv), d["mean_bytes_per_pixel_per_launch"], d["mean_bytes_per_launch"])
