@@ -1,7 +1,13 @@
 #!/usr/bin/env python3
-"""Soak test of the cross-frame overlap: two contexts fed the same device-produced moving-camera sequence, one with
-SvgfParams::inputs_ready = 1 (temporal pass of frame f+1 beside levels 2-5 of frame f), one fully ordered on the
-caller's stream.  Every output must be bit-identical.  usage: soak.py [--size 1920x1080] [--frames 2000]"""
+"""Soak test: two contexts fed the same device-produced moving-camera sequence on two streams, thousands of frames without
+a synchronisation between calls, parameters redrawn every K frames (--random K).
+  --pair default-fused (the default): context A runs the default path (temporal pass + lane kernels), context B forces the fused
+        temporal + first-level kernel (kernel_variant 6; it falls back to the unfused path by itself for parameter draws it
+        does not support).  Outputs must agree to 1e-5 relative at every check, history lengths bit for bit.
+  --pair default-gather: B runs the strict gather kernel on every level (kernel_variant 1): <= 1e-5.
+  --pair same: both default (since round 4 SvgfParams::inputs_ready is ignored, so this is the old overlap soak's shape):
+        bit-identical.
+usage: soak.py [--size 1920x1080] [--frames 2000] [--random 25] [--pair default-fused]"""
 import argparse
 import os
 import sys
@@ -18,13 +24,15 @@ def main():
     ap.add_argument("--random", type=int, default=0, metavar="K",
                     help="every K frames draw new parameters (levels 0..8, history level, paper steps, pre-blur, debug views, "
                          "temporal on/off) for both contexts")
+    ap.add_argument("--pair", default="default-fused", choices=["default-fused", "default-gather", "same"])
     a = ap.parse_args()
     import torch
     pkg = ge.load_package()
     W, H = map(int, a.size.split("x"))
     da, db = pkg.Denoiser(W, H), pkg.Denoiser(W, H)
+    vb = {"default-fused": 6, "default-gather": 1, "same": 0}[a.pair]
     pa = pkg.reference_defaults().set(temporal_enable=1, spatial_enable=1, atrous_nlevel=5, history_level=1, inputs_ready=1)
-    pb = pkg.reference_defaults().set(temporal_enable=1, spatial_enable=1, atrous_nlevel=5, history_level=1, inputs_ready=0)
+    pb = pkg.reference_defaults().set(temporal_enable=1, spatial_enable=1, atrous_nlevel=5, history_level=1, inputs_ready=0, kernel_variant=vb)
     nbuf = 64    # a 64-frame moving-camera sequence produced up front and replayed, so calls go back to back
     rgb = [torch.empty((H, W, 3), dtype=torch.float32, device="cuda") for _ in range(nbuf)]
     gb = [torch.empty((H * W * 52,), dtype=torch.uint8, device="cuda") for _ in range(nbuf)]
@@ -36,7 +44,7 @@ def main():
     oa = [torch.empty((H, W, 3), dtype=torch.float32, device="cuda") for _ in range(2)]
     ob = [torch.empty((H, W, 3), dtype=torch.float32, device="cuda") for _ in range(2)]
     sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
-    bad = 0
+    bad, worst = 0, 0.0
     import random
     rng = random.Random(20260928)
     for f in range(a.frames):
@@ -52,13 +60,20 @@ def main():
         db.denoise(ob[f & 1], rgb[k], gb[k], cams[k], pb, stream=sb)
         if f % 97 == 96 or f == a.frames - 1:
             torch.cuda.synchronize()
-            same = bool(torch.equal(oa[f & 1], ob[f & 1]))
+            if a.pair == "same":
+                same = bool(torch.equal(oa[f & 1], ob[f & 1]))
+            else:
+                den = torch.clamp(torch.abs(oa[f & 1]), min=1e-3)
+                err = float((torch.abs(oa[f & 1] - ob[f & 1]) / den).max())
+                worst = max(worst, err)
+                same = err <= 1e-5 and bool((da.read_state(0) == db.read_state(0)).all())
             fin = bool(torch.isfinite(oa[f & 1]).all())
             if not (same and fin):
                 bad += 1
-                print(f"frame {f}: identical={same} finite={fin}")
+                print(f"frame {f}: agree={same} finite={fin} params nlevel={pa.atrous_nlevel} hist={pa.history_level} paper={pa.paper_steps} view={pa.right_view_option} t={pa.temporal_enable} s={pa.spatial_enable}")
     torch.cuda.synchronize()
-    print(f"soak {W}x{H}, {a.frames} frames, overlap vs ordered: {'OK, bit-identical at every check' if bad == 0 else str(bad) + ' MISMATCHES'}")
+    print(f"soak {W}x{H}, {a.frames} frames, {a.pair}: " + (f"OK at every check (worst relative difference {worst:.2e}, history lengths identical)" if bad == 0 and a.pair != "same"
+          else "OK, bit-identical at every check" if bad == 0 else str(bad) + " MISMATCHES"))
     da.free(); db.free()
     sys.exit(1 if bad else 0)
 
