@@ -20,6 +20,9 @@
 // 5.8, profiles/r04_exp_fused_*.log: 176 us in its last version against 42.7 for the plain level, i.e. the fused kernel LOSES to
 // temporal pass + level, 55 + 46 us): with this factor the automatic choice never fuses; kernel_variant 6 forces it
 static const double kFusedRowFactor = 4.1;
+// the prepare pass of the non-temporal mode fused into the first level (svgf_atrous_fused.hip, FUSED = 3): on by default where the
+// first level runs the lane kernel anyway (measured: profiles/r04_exp_prepare_fused.log)
+static const bool kPrepareFusedByDefault = true;
 
 struct svgf_ctx {
     int device, W, H;
@@ -516,7 +519,20 @@ static int denoise_frame(svgf_ctx *c, void *out_rgb_dev, const void *in_rgb_dev,
                                                                      c->W, c->H, p->spatial_variance_frames, s));
         }
     } else {
-        LAUNCH(SVGF_KERNEL_PREPARE, launch_prepare(in, g, c->cv[acc], c->nrm[gnew], c->gid[gnew], c->pos[gnew], c->W, c->H, s));
+        // Non-temporal mode.  On the AoS boundary the prepare pass (variance = 10, colour copy, G-buffer split) is loads and
+        // stores only and rides in the first level's loader waves when the cascade starts with the lane kernel at step 2
+        // (svgf_atrous_fused.hip, FUSED = 3): no prepare launch, no colour plane written and read back.
+        t.in_rgb = in; t.gbuf = g; t.cv_acc = c->cv[acc];
+        t.nrm_cur = c->nrm[gnew]; t.gid_cur = c->gid[gnew]; t.pos_cur = c->pos[gnew];
+        t.W = c->W; t.H = c->H;
+        if (g && cascade && (p->kernel_variant == 0 || p->kernel_variant == 6) && !p->paper_steps) {
+            AtrousArgs probe;
+            memset(&probe, 0, sizeof(probe));
+            probe.W = c->W; probe.H = c->H; probe.step = 2;
+            fused = atrous_prepare_fused_supported(probe, t) && atrous_strip_supported(probe) && atrous_lane_supported(probe) &&
+                    (p->kernel_variant == 6 || (kPrepareFusedByDefault && lane_pays(c, probe)));
+        }
+        if (!fused) LAUNCH(SVGF_KERNEL_PREPARE, launch_prepare(in, g, c->cv[acc], c->nrm[gnew], c->gid[gnew], c->pos[gnew], c->W, c->H, s));
     }
     c->vp_valid &= ~(1u << acc);     // the temporal / prepare pass writes no variance plane: the first level gathers cv.w
     c->acc = acc;
@@ -604,7 +620,8 @@ static int denoise_frame(svgf_ctx *c, void *out_rgb_dev, const void *in_rgb_dev,
                 // the accumulated plane itself is only written when something besides this level reads it: a later frame (the
                 // history is not this level's output) or a test (svgf_set_capture)
                 t.cv_acc = (!keep || c->capture) ? c->cv[acc] : nullptr;
-                LAUNCH(SVGF_KERNEL_FUSED, launch_atrous_fused(a, t, s));
+                if (p->temporal_enable) LAUNCH(SVGF_KERNEL_FUSED, launch_atrous_fused(a, t, s));
+                else LAUNCH(SVGF_KERNEL_FUSED, launch_atrous_prepare_fused(a, t, s));
                 if (c->capture) { HIPC(c, hipMemcpyAsync(c->cv_capture, c->cv[acc], c->n * sizeof(float4), hipMemcpyDeviceToDevice, s)); }
                 break;
             case K_LANE:    LAUNCH(SVGF_KERNEL_ATROUS, launch_atrous_lane(a, s)); break;     // steps 2 .. 32: symmetric terms evaluated once

@@ -13,6 +13,8 @@
 //
 // Also here: the same two-y-phase geometry WITHOUT the fusion (kernel_variant 5), the A/B partner that separates what the
 // geometry costs from what the fusion brings.
+#include <cstring>
+
 #include "svgf_atrous_lane_impl.h"
 
 // byte offset of a context plane from the context's allocation; false when it does not fit 32 bits
@@ -71,6 +73,26 @@ hipError_t launch_atrous_fused(const AtrousArgs &a, const TemporalArgs &t, hipSt
     if (!t.dump || !fused_offsets(t, &f)) return hipErrorInvalidValue;
     if (t.gbuf) return a.dst ? launch_lane_cfg<1, true, 1, 1, 1>(a, s, &f) : launch_lane_cfg<1, false, 1, 1, 1>(a, s, &f);
     return a.dst ? launch_lane_cfg<1, true, 1, 1, 2>(a, s, &f) : launch_lane_cfg<1, false, 1, 1, 2>(a, s, &f);
+}
+
+// Non-temporal mode (reference EstimateVariance :320-329 + colour copy :370, and the G-buffer split of this library's prepare
+// kernel) fused into the first level: FUSED = 3 of the lane kernel.  Unlike the temporal pass this is loads and stores only — the
+// loaders fetch the 1-spp colour and the texel instead of three planes and write the split planes of the pixels their workgroup
+// owns — so it fits the loader waves: one launch and 108 B/px of traffic less per frame.
+bool atrous_prepare_fused_supported(const AtrousArgs &a, const TemporalArgs &t)
+{
+    if (a.step != 2 || !t.gbuf || !t.in_rgb) return false;          // the AoS boundary, the reference's first level
+    if ((long long)a.W * a.H * 52 >= (1LL << 32)) return false;      // 32-bit byte offsets into the texel array
+    return t.nrm_cur && t.pos_cur && t.gid_cur;
+}
+
+hipError_t launch_atrous_prepare_fused(const AtrousArgs &a, const TemporalArgs &t, hipStream_t s)
+{
+    if (!atrous_prepare_fused_supported(a, t)) return hipErrorInvalidValue;
+    LaneFused f;
+    memset(&f, 0, sizeof(f));
+    static_cast<TemporalArgs &>(f) = t;
+    return a.dst ? launch_lane_cfg<1, true, 1, 0, 3>(a, s, &f) : launch_lane_cfg<1, false, 1, 0, 3>(a, s, &f);
 }
 
 // step 2 with both y-phases in one workgroup, not fused (reads the accumulated plane like every other level)

@@ -74,7 +74,10 @@ struct LaneGeom {
 struct Px {
     float4 cv;
     float nx, ny, nz, px, py, pz;
-    int lds_off;   // byte offset of the record in the ring; bit 31 or bit 30 set = out-of-image pixel
+    int lds_off;   // byte offset of the record in the ring; bit 31 or bit 30 set = out-of-image pixel; bit 29 (FUSED == 3 only): the
+                   // workgroup owns the pixel (it writes the pixel's split G-buffer planes)
+    int gid;       // FUSED == 3 only: the texel's geomId, and the pixel index the planes are written at
+    unsigned q;
 };
 
 __device__ __forceinline__ float lum_f64(float r, float g, float b)
@@ -139,7 +142,10 @@ struct LaneFused : TemporalArgs {
 // grows from ~300 to ~600 of 5 300 ticks), one load 1-4 us (its first use waits, in order, for the previous row's stores),
 // against ~3 us the four evaluations are worth, and at 4K the two extra planes (266 MB per level) meet an HBM that is no longer
 // half idle.  Off by default (environment SVGF_REUSE=1 turns it on); kept because it is correct and small.
-// FUSED: 0 no, 1 fused temporal pass reading the AoS G-buffer, 2 fused temporal pass reading the producer's planes
+// FUSED: 0 no, 1 fused temporal pass reading the AoS G-buffer, 2 fused temporal pass reading the producer's planes,
+//        3 fused PREPARE pass (non-temporal mode, reference EstimateVariance :320-329 + :370 and the G-buffer split): the loaders
+//          stage colour from the 1-spp input, variance = 10 and normal / position from the AoS texels, and write the split planes
+//          of the pixels the workgroup owns; standard geometry (one y-phase per workgroup), the pre-blur rows are the constant 10
 template <int LOG2S, bool HASVAR, int LOG2P = LOG2S, int LOG2Y = 0, int FUSED = 0, int REUSE = 0>
 __global__ __launch_bounds__(NT) void k_atrous_lane(AtrousArgs a, LaneGeom gm, std::conditional_t<FUSED != 0, LaneFused, LaneNoTemporal> ta)
 {
@@ -149,7 +155,9 @@ __global__ __launch_bounds__(NT) void k_atrous_lane(AtrousArgs a, LaneGeom gm, s
     constexpr int YP = 1 << LOG2Y;               // y-phases held by one workgroup
     constexpr bool CHUNKED = (P < S);
     static_assert(YP == 1 || (YP == 2 && S == 2 && P == S), "two y-phases per workgroup: step 2 only");
-    static_assert(FUSED == 0 || YP == 2, "the fused temporal pass needs the pre-blur rows in the ring");
+    constexpr bool TFUSED = (FUSED == 1 || FUSED == 2), PFUSED = (FUSED == 3);
+    static_assert(!TFUSED || YP == 2, "the fused temporal pass needs the pre-blur rows in the ring");
+    static_assert(!PFUSED || (YP == 1 && P == S), "the fused prepare pass uses the plain geometry of steps <= 8");
     constexpr int WPP = NWC / (P * YP);          // waves per x-phase (and y-phase)
     constexpr int TXW = TXO / YP;                // output pixel columns per workgroup
     constexpr int M = LOUT * WPP + 4;            // lattice columns per phase in the ring (2 halo either side)
@@ -251,6 +259,25 @@ __global__ __launch_bounds__(NT) void k_atrous_lane(AtrousArgs a, LaneGeom gm, s
     auto bel_of = [&](int xb) { return (xb & (S - 1)) * BM + (xb >> LOG2S); };
 
     // ---------------- staging (global -> registers -> LDS ring), branch-free, coordinates clamped ----------------
+    // one pixel's loads.  PFUSED: the level's input does not exist as planes yet — colour comes from the 1-spp image, the variance
+    // is the constant of the non-temporal mode (:327), normal / position / geomId from the boundary's 52-byte texel
+    auto stage_load = [&](Px &lp, unsigned q) {
+        if constexpr (PFUSED) {
+            const float *c3 = reinterpret_cast<const float *>(reinterpret_cast<const char *>(ta.in_rgb) + q * 12u);
+            const float *g = reinterpret_cast<const float *>(reinterpret_cast<const char *>(ta.gbuf) + q * 52u);
+            lp.cv = make_float4(c3[0], c3[1], c3[2], 10.0f);
+            lp.nx = g[0]; lp.ny = g[1]; lp.nz = g[2];
+            lp.px = g[3]; lp.py = g[4]; lp.pz = g[5];
+            lp.gid = __float_as_int(g[12]);
+            lp.q = q;
+        } else {
+            lp.cv = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(a.src) + q * 16u);
+            const float *n = reinterpret_cast<const float *>(reinterpret_cast<const char *>(a.nrm) + q * 12u);
+            const float *p = reinterpret_cast<const float *>(reinterpret_cast<const char *>(a.pos) + q * 12u);
+            lp.nx = n[0]; lp.ny = n[1]; lp.nz = n[2];
+            lp.px = p[0]; lp.py = p[1]; lp.pz = p[2];
+        }
+    };
     auto rows_load = [&](auto &px, int br_first, int nrows, int wi, int nw) {
         constexpr int N = sizeof(px) / sizeof(px[0]);
         const int total = nrows * YP * RW;
@@ -263,12 +290,12 @@ __global__ __launch_bounds__(NT) void k_atrous_lane(AtrousArgs a, LaneGeom gm, s
             const int xs = xs_of(xi);
             const bool ok = (br >= 0) && (y < H) && (xs >= 0) && (xs < W);
             px[m].lds_off = ((slot_mod(br) * YP + yp) * ROWB + rec_of(xi)) | (ok ? 0 : (int)0x80000000);
+            if constexpr (PFUSED) {      // owned: one of this workgroup's output pixels (the thread that stages index `idx` exists once)
+                const bool owned = ok && (wi + m * nw < total) && (br >= b0) && (br < b1) && (xi >= 2 * S) && (xi < 2 * S + TXO);
+                px[m].lds_off |= owned ? 0x20000000 : 0;
+            }
             const unsigned q = (unsigned)min(max(y, 0), H - 1) * (unsigned)W + (unsigned)min(max(xs, 0), W - 1);
-            px[m].cv = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(a.src) + q * 16u);
-            const float *n = reinterpret_cast<const float *>(reinterpret_cast<const char *>(a.nrm) + q * 12u);
-            const float *p = reinterpret_cast<const float *>(reinterpret_cast<const char *>(a.pos) + q * 12u);
-            px[m].nx = n[0]; px[m].ny = n[1]; px[m].nz = n[2];
-            px[m].px = p[0]; px[m].py = p[1]; px[m].pz = p[2];
+            stage_load(px[m], q);
         }
     };
     auto rows_store = [&](const auto &px) {
@@ -276,14 +303,27 @@ __global__ __launch_bounds__(NT) void k_atrous_lane(AtrousArgs a, LaneGeom gm, s
         const float inf = __builtin_huge_valf();
 #pragma unroll
         for (int m = 0; m < N; m++) {
-            const bool ok = (unsigned)px[m].lds_off < 0x40000000u;
+            const bool ok = PFUSED ? ((px[m].lds_off & (int)0xC0000000) == 0) : ((unsigned)px[m].lds_off < 0x40000000u);
             const float lum = lum_f64(px[m].cv.x, px[m].cv.y, px[m].cv.z);
             const float mag = fabsf(px[m].nx) + fabsf(px[m].ny) + fabsf(px[m].nz) + fabsf(px[m].px) + fabsf(px[m].py) + fabsf(px[m].pz);
             if (!(mag < inf)) *nan_seen = 1;
-            char *d = smem + (px[m].lds_off & 0x3fffffff);
+            char *d = smem + (px[m].lds_off & (PFUSED ? 0x1fffffff : 0x3fffffff));
             *reinterpret_cast<float4 *>(d) = make_float4(px[m].nx, px[m].px, px[m].ny, px[m].py);
             *reinterpret_cast<float4 *>(d + 16) = make_float4(px[m].nz, px[m].pz, ok ? lum : inf, 0.0f);
             *reinterpret_cast<float4 *>(d + 32) = ok ? px[m].cv : make_float4(0.f, 0.f, 0.f, 0.f);
+            if constexpr (PFUSED) {
+                // the planes the rest of the frame (levels >= 2) and the next frame (previous normals / geomIds) read: what the
+                // prepare kernel would have written (launch_prepare), by the one workgroup that owns the pixel
+                if (px[m].lds_off & 0x20000000) {
+                    const unsigned q = px[m].q;
+                    float *n = reinterpret_cast<float *>(reinterpret_cast<char *>(ta.nrm_cur) + q * 12u);
+                    float *p = reinterpret_cast<float *>(reinterpret_cast<char *>(ta.pos_cur) + q * 12u);
+                    n[0] = px[m].nx; n[1] = px[m].ny; n[2] = px[m].nz;
+                    p[0] = px[m].px; p[1] = px[m].py; p[2] = px[m].pz;
+                    ta.gid_cur[q] = px[m].gid;
+                    if (ta.cv_acc) ta.cv_acc[q] = px[m].cv;        // only when something besides this level reads the plane
+                }
+            }
         }
     };
     // pre-blur rows y-1, y+1 of output row bo (3x3 variance blur, :102-118); element e = d * BW + xb
@@ -297,7 +337,10 @@ __global__ __launch_bounds__(NT) void k_atrous_lane(AtrousArgs a, LaneGeom gm, s
                 const int d = e / BW, xb = e - d * BW;
                 const int y = phase + (bo << LOG2S) + (d ? 1 : -1);
                 const int xs = x0 - 1 + xb;
-                if (y >= 0 && y < H && xs >= 0 && xs < W && bo < b1) v[m] = *reinterpret_cast<const float *>(vbase + (unsigned)y * vys + (unsigned)xs * vxs);
+                if (y >= 0 && y < H && xs >= 0 && xs < W && bo < b1) {
+                    if constexpr (PFUSED) v[m] = 10.0f;         // the variance of every pixel in the non-temporal mode (:327)
+                    else v[m] = *reinterpret_cast<const float *>(vbase + (unsigned)y * vys + (unsigned)xs * vxs);
+                }
             }
         }
     };
@@ -363,6 +406,7 @@ __global__ __launch_bounds__(NT) void k_atrous_lane(AtrousArgs a, LaneGeom gm, s
     float lbv[MBL];
     VB lvb;
     int l_xq[ML], l_lds[ML];
+    bool l_own[ML];                   // PFUSED: the staged column is one of the workgroup's output columns, inside the image, and this thread's own
     int b_voff[MBL], b_lds[MBL];      // b_voff < 0: element does not exist or its column is outside the image
     bool b_d[MBL];
     // (filled in inside the prologue, between the issue of its global loads and their use)
@@ -374,6 +418,7 @@ __global__ __launch_bounds__(NT) void k_atrous_lane(AtrousArgs a, LaneGeom gm, s
                 const int xs = xs_of(xi);
                 l_xq[m] = min(max(xs, 0), W - 1);
                 l_lds[m] = rec_of(xi) | ((xs >= 0 && xs < W) ? 0 : 0x40000000);
+                l_own[m] = (llane + m * kLoaderGroup < RW) && xs >= 0 && xs < W && xi >= 2 * S && xi < 2 * S + TXO;
             }
             if constexpr (!CHUNKED && YP == 1) {
 #pragma unroll
@@ -403,11 +448,8 @@ __global__ __launch_bounds__(NT) void k_atrous_lane(AtrousArgs a, LaneGeom gm, s
                     const unsigned q = (unsigned)(rowq + l_xq[m]);
                     Px &lp = lpx[yp * ML + m];
                     lp.lds_off = ldsrow + l_lds[m];
-                    lp.cv = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(a.src) + q * 16u);
-                    const float *n = reinterpret_cast<const float *>(reinterpret_cast<const char *>(a.nrm) + q * 12u);
-                    const float *p = reinterpret_cast<const float *>(reinterpret_cast<const char *>(a.pos) + q * 12u);
-                    lp.nx = n[0]; lp.ny = n[1]; lp.nz = n[2];
-                    lp.px = p[0]; lp.py = p[1]; lp.pz = p[2];
+                    if constexpr (PFUSED) lp.lds_off |= (br < b1 && y < H && l_own[m]) ? 0x20000000 : 0;
+                    stage_load(lp, q);
                 }
             }
             if constexpr (YP > 1) {
@@ -419,7 +461,8 @@ __global__ __launch_bounds__(NT) void k_atrous_lane(AtrousArgs a, LaneGeom gm, s
                 const unsigned rm = (unsigned)min(max(ym, 0), H - 1) * vys, rp = (unsigned)min(max(yp, 0), H - 1) * vys;
 #pragma unroll
                 for (int m = 0; m < MBL; m++)
-                    lbv[m] = *reinterpret_cast<const float *>(vbase + (b_d[m] ? rp : rm) + (unsigned)max(b_voff[m], 0));
+                    if constexpr (PFUSED) lbv[m] = 10.0f;
+                    else lbv[m] = *reinterpret_cast<const float *>(vbase + (b_d[m] ? rp : rm) + (unsigned)max(b_voff[m], 0));
             }
         }
     };
@@ -512,11 +555,11 @@ __global__ __launch_bounds__(NT) void k_atrous_lane(AtrousArgs a, LaneGeom gm, s
     };
     // history planes are addressed as (the context's allocation) + 32-bit byte offset, see LaneFused
     [[maybe_unused]] auto t_ptr = [&](unsigned byte_off) -> const char * {
-        if constexpr (FUSED != 0) return reinterpret_cast<const char *>(ta.arena) + byte_off;
+        if constexpr (TFUSED) return reinterpret_cast<const char *>(ta.arena) + byte_off;
         else return nullptr;
     };
     [[maybe_unused]] auto t_wptr = [&](unsigned byte_off) -> char * {
-        if constexpr (FUSED != 0) return const_cast<char *>(reinterpret_cast<const char *>(ta.arena)) + byte_off;
+        if constexpr (TFUSED) return const_cast<char *>(reinterpret_cast<const char *>(ta.arena)) + byte_off;
         else return nullptr;
     };
     constexpr int kLdsDump = RING_BYTES + 32;          // 48 bytes nobody reads: the ring record of a thread's idle pixel slot
@@ -531,7 +574,7 @@ __global__ __launch_bounds__(NT) void k_atrous_lane(AtrousArgs a, LaneGeom gm, s
         flags = (ok ? 1 : 0) | (owned ? 2 : 0);
     };
     [[maybe_unused]] auto t_stage_a = [&](TA_ &t, unsigned p) __attribute__((always_inline)) {
-        if constexpr (FUSED != 0) {
+        if constexpr (TFUSED) {
             // (unsigned 32-bit byte offsets: scalar base + vector offset addressing; W * H * 52 < 2^32 is checked by the launcher)
             if constexpr (FUSED == 1) {         // the boundary's AoS texels
                 const char *g = reinterpret_cast<const char *>(ta.gbuf) + __umul24(p, 52u);
@@ -551,7 +594,7 @@ __global__ __launch_bounds__(NT) void k_atrous_lane(AtrousArgs a, LaneGeom gm, s
     // (unconditional: a pixel that wants no history reprojects whatever its position is — NaN included — and reads clamped
     // addresses; nothing of it is used)
     [[maybe_unused]] auto t_stage_b = [&](const TA_ &araw, TB_ &b_, SvgfReproj &rp_out) __attribute__((always_inline)) {
-        if constexpr (FUSED != 0) {
+        if constexpr (TFUSED) {
             const TAu_ a_ = t_unpack(araw);
             const SvgfReproj rp = svgf_reproject(ta, a_.px, a_.py, a_.pz);
             rp_out = rp;
@@ -567,7 +610,7 @@ __global__ __launch_bounds__(NT) void k_atrous_lane(AtrousArgs a, LaneGeom gm, s
         }
     };
     [[maybe_unused]] auto t_stage_c1 = [&](const TA_ &araw, const TB_ &b_, const SvgfReproj &rp, int flags, unsigned p, TC_ &c_) __attribute__((always_inline)) {
-        if constexpr (FUSED != 0) {
+        if constexpr (TFUSED) {
             const TAu_ a_ = t_unpack(araw);
             c_.rgb = *reinterpret_cast<const v3f_u *>(reinterpret_cast<const char *>(ta.in_rgb) + __umul24(p, 12u));
             c_.rp = rp;
@@ -607,7 +650,7 @@ __global__ __launch_bounds__(NT) void k_atrous_lane(AtrousArgs a, LaneGeom gm, s
         }
     };
     [[maybe_unused]] auto t_stage_c2 = [&](const TA_ &araw, const TC_ &c_, int flags, unsigned p, int lds_off) __attribute__((always_inline)) {
-        if constexpr (FUSED != 0) {
+        if constexpr (TFUSED) {
             const TAu_ a_ = t_unpack(araw);
             const float lum = svgf_lum_strict(c_.rgb.x, c_.rgb.y, c_.rgb.z);
             SvgfHistSum hs = { 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f };
@@ -694,7 +737,7 @@ __global__ __launch_bounds__(NT) void k_atrous_lane(AtrousArgs a, LaneGeom gm, s
         }
     };
 
-    if constexpr (FUSED != 0) {
+    if constexpr (TFUSED) {
         // One software pipeline for the prologue and the loop, ONE pixel per thread and sub-step.  Pixel q of a thread:
         //   q = 0 .. 3     the ten prologue rows b0-2 .. b0+2 (both y-phases), dealt over all 768 threads, four pixels each;
         //   q >= 4         lattice row b0+3 + (q-4)/2, y-phase (q-4) & 1, at the staged column a LOADER thread owns.
@@ -1067,7 +1110,7 @@ __global__ __launch_bounds__(NT) void k_atrous_lane(AtrousArgs a, LaneGeom gm, s
 #pragma unroll 1
     for (int bw = b0 - 2; bw < b0; bw++) {
 #if SVGF_LANE_SPLIT_PROLOGUE
-        if constexpr (FUSED == 0) { if (bw == b0 - 1) __syncthreads(); }     // rows b0+1, b0+2 are published by the loader threads (see the prologue)
+        if constexpr (!TFUSED) { if (bw == b0 - 1) __syncthreads(); }     // rows b0+1, b0+2 are published by the loader threads (see the prologue)
 #endif
         const char *rowc = colbase + slot_of(bw) * RSTR + 2 * PXB;
         const v4f A = *reinterpret_cast<const v4f *>(rowc);
@@ -1391,7 +1434,7 @@ template <int LOG2S, bool HASVAR, int LOG2P = LOG2S, int LOG2Y = 0, int FUSED = 
 hipError_t launch_lane_cfg(const AtrousArgs &a, hipStream_t s, const LaneFused *ta = nullptr)
 {
     constexpr int S = 1 << LOG2S, P = 1 << LOG2P, YP = 1 << LOG2Y, M = LOUT * (NWC / (P * YP)) + 4, MP = (P == 4) ? M + 2 : ((M * 12 % 64 == 0) ? M + 1 : M), BM = (BW + S - 1) / S;
-    constexpr size_t kLds = (size_t)R * YP * P * MP * PXB + (size_t)2 * (YP > 1 ? 0 : (P < S ? P * M : 2 * S * BM)) * 4 + 16 + (FUSED != 0 ? 80 : 0);
+    constexpr size_t kLds = (size_t)R * YP * P * MP * PXB + (size_t)2 * (YP > 1 ? 0 : (P < S ? P * M : 2 * S * BM)) * 4 + 16 + ((FUSED == 1 || FUSED == 2) ? 80 : 0);
     const size_t lds = kLds;
     static_assert(kLds <= 160 * 1024, "LDS budget");
     static SvgfLaunchCache cache;
@@ -1442,7 +1485,7 @@ hipError_t launch_lane_cfg(const AtrousArgs &a, hipStream_t s, const LaneFused *
                             h[(w * 16) * 8 + 0] - h[(w * 16) * 8 + 7]);
                 for (int it = 0; it < 8 && h[(w * 16 + it) * 8]; it++) {
                     unsigned long long *t = &h[(w * 16 + it) * 8];
-                    if (w >= NWC && FUSED != 0) fprintf(stderr, "  loader %2d it %2d: t0=%6llu first pixel: C2 (blend, commit) %5llu C1 (consistency, history request) %5llu B %5llu A %5llu | second pixel %6llu | barrier %5llu\n", w, it,
+                    if (w >= NWC && (FUSED == 1 || FUSED == 2)) fprintf(stderr, "  loader %2d it %2d: t0=%6llu first pixel: C2 (blend, commit) %5llu C1 (consistency, history request) %5llu B %5llu A %5llu | second pixel %6llu | barrier %5llu\n", w, it,
                                                    t[0] - h[0], t[1] - t[0], t[2] - t[1], t[3] - t[2], t[4] - t[3], t[5] - t[4], t[6] - t[5]);
                     else if (w >= NWC) fprintf(stderr, "  loader %2d it %2d: t0=%6llu work %6llu barrier %5llu\n", w, it, t[0] - h[0], t[5] - t[0], t[6] - t[5]);
                     else fprintf(stderr, "  wave %2d it %2d: t0=%6llu centre %5llu back rows %5llu own %5llu fwd rows %5llu out %5llu barrier %5llu\n", w, it,

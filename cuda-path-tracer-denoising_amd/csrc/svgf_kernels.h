@@ -138,6 +138,9 @@ double     atrous_lane_estimate_us(const AtrousArgs &a, int n_cu);
 hipError_t launch_atrous_fused(const AtrousArgs &a, const TemporalArgs &t, hipStream_t s);
 bool       atrous_fused_supported(const AtrousArgs &a, const TemporalArgs &t);
 double     atrous_fused_estimate_us(const AtrousArgs &a, int n_cu);
+// non-temporal mode: the prepare pass (variance fill + G-buffer split) fused into the first level (step 2, AoS boundary)
+hipError_t launch_atrous_prepare_fused(const AtrousArgs &a, const TemporalArgs &t, hipStream_t s);
+bool       atrous_prepare_fused_supported(const AtrousArgs &a, const TemporalArgs &t);
 hipError_t launch_atrous_lane_2y(const AtrousArgs &a, hipStream_t s);  // step 2, both y-phases per workgroup, not fused (A/B)
 hipError_t launch_atrous_lattice(const AtrousArgs &a, hipStream_t s);  // lattice sub-images in LDS (steps >= 64)
 bool       atrous_lattice_supported(const AtrousArgs &a);
