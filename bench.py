@@ -348,6 +348,12 @@ def main():
     tm_all.stop()
     iso_atrous_ms = [ms for s in range(den.profile_frames()) for kind, ms in den.profile_read(s)
                      if kind == pkg.binding.KERNEL_ATROUS]
+    # config1 (non-temporal, ONE level): that level carries the prepare pass in its loader waves (one launch per frame, kind FUSED):
+    # it is the a-trous launch of this configuration, timed with the prepare work inside it
+    level_is_fused = not atrous_ms and bool(fused_ms)
+    if level_is_fused:
+        atrous_ms = list(fused_ms)
+        iso_atrous_ms = [ms for s in range(den.profile_frames()) for kind, ms in den.profile_read(s) if kind == pkg.binding.KERNEL_FUSED]
 
     if rank == 0:
         traffic, traffic_note = None, "no PMC record"
@@ -396,6 +402,7 @@ def main():
                          "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, profiles/pmc_traffic.json (FETCH x2 per MI355X_MICROARCH.md)",
                          "kernel": "one plain a-trous level: k_atrous_lane (steps 4-32 when the first level is fused with the temporal pass, else 2-32; k_atrous_strip where the library's cost model prefers it); mean over those launches of a frame; the fused temporal + first-level launch is reported under kernels_us", "bytes_per_launch": ATROUS_BYTES_PER_PIXEL * W * H,
                          "mean_launch_us": round(a_ms * 1e3, 2), "launches_timed": len(atrous_ms),
+                         "launch_includes_fused_prepare_pass": level_is_fused,
                          "note": "everything ordered on one stream; durations are the dispatches' own begin / end timestamps (HIP events attached by hipExtLaunchKernelGGL on the launch stream, every 8th timed frame); 'isolated' repeats the measurement on every kernel of 16 frames",
                          "isolated": {"mean_launch_us": round(iso_us, 2), "achieved": round(iso_gbs, 1),
                                       "frac": round(iso_gbs / HBM_PEAK_GBS, 4), "launches_timed": len(iso_atrous_ms)},
