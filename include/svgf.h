@@ -87,13 +87,17 @@ typedef struct SvgfParams {
                                  2 LDS strip kernel for every step 2-32 (error if a step is unsupported, raised before
                                  anything is enqueued), 3 retired (was an experimental shared-weight kernel, now under
                                  tools/experiments/; SVGF_ERR_INVALID_ARG), 4 lane-marching kernel wherever it is supported (steps
-                                 2-32) whatever the image width, strip / lattice for the rest; the temporal pass is its own
-                                 kernel,
+                                 2-32) whatever the image width, strip / lattice for the rest; the temporal (or prepare) pass is
+                                 its own kernel,
                                  5 as 4 with the step-2 level on the two-y-phase geometry of the fused kernel, not fused (A/B),
                                  6 as 4 with the temporal pass fused into the first level on every frame that can be fused
                                  (temporal and spatial on, no debug view, reference steps, no reproj_position_tol /
-                                 spatial_variance_frames), whatever the cost model says.
-                                 0 fuses where 6 would and the launch-geometry cost model says it pays (ABI 0.6) */
+                                 spatial_variance_frames), whatever the cost model says; on NON-temporal frames the prepare
+                                 pass (variance fill + G-buffer split) is fused into the first level instead.
+                                 0 fuses the temporal pass where 6 would and the cost model says it pays (at the measured speed
+                                 of that kernel: never), and the prepare pass of non-temporal frames whenever the first level
+                                 runs the lane kernel at step 2 on the AoS boundary (measured: +39 % on BASELINE configs[0])
+                                 (ABI 0.6) */
     int   inputs_ready;       /* accepted and IGNORED since ABI 0.6 (everything is ordered on `stream`).  Rounds 1-3: 1 let the
                                  temporal pass of this frame run on an internal stream beside the previous frame's trailing
                                  a-trous levels; it lost 3-8 % once the lane kernel ran every level, and the fused first level
@@ -188,7 +192,7 @@ int svgf_set_capture(svgf_ctx *ctx, int on);
 #define SVGF_KERNEL_ATROUS     3
 #define SVGF_KERNEL_DEBUGVIEW  4
 #define SVGF_KERNEL_COPYOUT    5
-#define SVGF_KERNEL_FUSED      6   /* temporal pass + first a-trous level in one launch (ABI 0.6) */
+#define SVGF_KERNEL_FUSED      6   /* temporal (or, on non-temporal frames, prepare) pass + first a-trous level in one launch (ABI 0.6) */
 /* Timing source: an event pair attached to each kernel dispatch (hipExtLaunchKernelGGL): the kernel's own begin / end
  * timestamps, nothing recorded on the stream.
  * svgf_profile_stride(ctx, k): time only every k-th frame (k >= 1, default 1).
