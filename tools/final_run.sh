@@ -13,6 +13,7 @@ python bench.py --no-cpu-baseline --planar-inputs > $O/bench_line_planar_inputs.
 python bench.py --no-cpu-baseline --config 1080p-moving > $O/bench_line_1080p_moving.json 2>/dev/null
 python bench.py --no-cpu-baseline --config 4k-static > $O/bench_line_4k_static.json 2>/dev/null
 python bench.py --config config1 > $O/bench_line_config1.json 2>/dev/null
+python bench.py --config config1 --no-cpu-baseline --kernel-variant 4 > $O/bench_line_config1_unfused_prepare.json 2>/dev/null
 python bench.py --steps 200 --warmup 5 --no-cpu-baseline > $O/bench_line_200_steps.json 2>/dev/null
 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --kernel-variant 6 > $O/bench_line_fused_forced.json 2>/dev/null
 python tools/clock_states.py --json $O/clock_states.json > $O/clock_states.txt 2>/dev/null
