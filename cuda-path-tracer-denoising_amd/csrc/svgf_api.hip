@@ -23,6 +23,8 @@ static const double kFusedRowFactor = 4.1;
 // the prepare pass of the non-temporal mode fused into the first level (svgf_atrous_fused.hip, FUSED = 3): on by default where the
 // first level runs the lane kernel anyway (measured: profiles/r04_exp_prepare_fused.log)
 static const bool kPrepareFusedByDefault = true;
+// temporal frames: only the G-buffer split fused into the first level (FUSED = 4); default decided by measurement
+static const bool kSplitFusedByDefault = false;
 
 struct svgf_ctx {
     int device, W, H;
@@ -36,6 +38,7 @@ struct svgf_ctx {
     size_t arena_bytes;
     float4 *tp[2];         // cross-level reuse of the geometric terms: four terms per pixel, written by level L for level L+1 (lane kernels
                            // only, svgf_atrous_lane_reuse.hip); allocated when a frame first has two consecutive lane-kernel levels
+    int use_split_fused;   // temporal frames: the G-buffer split in the first level's loaders (environment SVGF_SPLIT_FUSED=0/1 overrides the default)
     int use_reuse;         // 1 only for A/B measurements (environment SVGF_REUSE at svgf_create): measured a loss, profiles/r04_ab_reuse_*.log
     int n_cu;              // compute units of the context's device (launch-geometry cost model of the kernel choice)
     signed char lane_cheaper[8];   // per log2(step): -1 not evaluated yet, 1 the lane kernel's estimate is the lower one
@@ -207,6 +210,7 @@ extern "C" int svgf_create(int device, int width, int height, svgf_ctx **out)
     for (int k = 0; k < 16; k++) c->view_prev[k] = (k % 5 == 0) ? 1.0f : 0.0f;
     c->use_vplane = getenv("SVGF_NO_VARIANCE_PLANE") ? 0 : 1;
     c->use_reuse = getenv("SVGF_REUSE") ? 1 : 0;
+    { const char *e = getenv("SVGF_SPLIT_FUSED"); c->use_split_fused = e ? (atoi(e) != 0) : kSplitFusedByDefault; }
     if (hipDeviceGetAttribute(&c->n_cu, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || c->n_cu < 8) c->n_cu = 256;
     memset(c->lane_cheaper, -1, sizeof(c->lane_cheaper));
     c->fuse_pays = -1;
@@ -494,7 +498,7 @@ static int denoise_frame(svgf_ctx *c, void *out_rgb_dev, const void *in_rgb_dev,
     const bool cascade = !(p->right_view_option == 1 || p->right_view_option == 2 || p->atrous_nlevel == 0 || !p->spatial_enable);
     TemporalArgs t;
     memset(&t, 0, sizeof(t));
-    bool fused = false;
+    bool fused = false, split_fused = false;
     if (p->temporal_enable) {
         t.in_rgb = in; t.gbuf = g; t.cv_hist = c->cv[c->hist]; t.cv_acc = c->cv[acc];
         t.mom_hist = c->mom[c->cur]; t.mom_acc = c->mom[1 - c->cur];
@@ -512,6 +516,15 @@ static int denoise_frame(svgf_ctx *c, void *out_rgb_dev, const void *in_rgb_dev,
             probe.W = c->W; probe.H = c->H; probe.step = 2;
             fused = atrous_fused_supported(probe, t) && (p->kernel_variant == 6 || fuse_pays(c, probe));
         }
+        // The G-buffer split alone can ride in the first level's loaders (svgf_atrous_fused.hip, FUSED = 4): the temporal pass then
+        // writes 28 B/px less.  Only where that level runs the lane kernel at step 2 and nothing reads the planes before it does.
+        if (!fused && c->use_split_fused && g && cascade && p->kernel_variant == 0 && !p->paper_steps && p->spatial_variance_frames <= 0) {
+            AtrousArgs probe;
+            memset(&probe, 0, sizeof(probe));
+            probe.W = c->W; probe.H = c->H; probe.step = 2; probe.src = c->cv[acc];
+            split_fused = atrous_split_fused_supported(probe, t) && atrous_strip_supported(probe) && atrous_lane_supported(probe) && lane_pays(c, probe);
+        }
+        t.skip_split = split_fused ? 1 : 0;
         if (!fused) {
             LAUNCH(SVGF_KERNEL_TEMPORAL, launch_temporal(t, s, false));
             if (p->spatial_variance_frames > 0)      // f4 extension: spatial variance estimate for short histories (its own profiling slot, same kind)
@@ -615,6 +628,10 @@ static int denoise_frame(svgf_ctx *c, void *out_rgb_dev, const void *in_rgb_dev,
                 }
             }
             prev_terms = terms_out; prev_step = a.step;
+            if (split_fused && level == 1 && which != K_LANE) {      // (the decision above and the kernel choice here use the same model)
+                snprintf(c->err, sizeof(c->err), "svgf_denoise: internal error, the G-buffer split was left to a first level that does not run the lane kernel");
+                return SVGF_ERR_HIP;
+            }
             switch (which) {
             case K_FUSED:
                 // the accumulated plane itself is only written when something besides this level reads it: a later frame (the
@@ -624,7 +641,10 @@ static int denoise_frame(svgf_ctx *c, void *out_rgb_dev, const void *in_rgb_dev,
                 else LAUNCH(SVGF_KERNEL_FUSED, launch_atrous_prepare_fused(a, t, s));
                 if (c->capture) { HIPC(c, hipMemcpyAsync(c->cv_capture, c->cv[acc], c->n * sizeof(float4), hipMemcpyDeviceToDevice, s)); }
                 break;
-            case K_LANE:    LAUNCH(SVGF_KERNEL_ATROUS, launch_atrous_lane(a, s)); break;     // steps 2 .. 32: symmetric terms evaluated once
+            case K_LANE:
+                if (split_fused && level == 1) LAUNCH(SVGF_KERNEL_ATROUS, launch_atrous_split_fused(a, t, s));
+                else LAUNCH(SVGF_KERNEL_ATROUS, launch_atrous_lane(a, s));
+                break;     // steps 2 .. 32: symmetric terms evaluated once
             case K_LANE2Y:  LAUNCH(SVGF_KERNEL_ATROUS, launch_atrous_lane_2y(a, s)); break;  // A/B partner of the fused kernel's geometry
             case K_STRIP:   LAUNCH(SVGF_KERNEL_ATROUS, launch_atrous_strip(a, s)); break;
             case K_LATTICE: LAUNCH(SVGF_KERNEL_ATROUS, launch_atrous_lattice(a, s)); break;

@@ -95,6 +95,25 @@ hipError_t launch_atrous_prepare_fused(const AtrousArgs &a, const TemporalArgs &
     return a.dst ? launch_lane_cfg<1, true, 1, 0, 3>(a, s, &f) : launch_lane_cfg<1, false, 1, 0, 3>(a, s, &f);
 }
 
+// Temporal frames on the AoS boundary: only the G-buffer SPLIT moves into the first level's loaders (FUSED = 4).  The temporal
+// pass keeps its arithmetic and its accumulated plane but no longer writes NRM / POS / GID (28 of its 56 B/px of stores); the
+// loaders read the texel instead of the two planes and write the planes for the pixels their workgroup owns.
+bool atrous_split_fused_supported(const AtrousArgs &a, const TemporalArgs &t)
+{
+    if (a.step != 2 || !t.gbuf || !a.src) return false;
+    if ((long long)a.W * a.H * 52 >= (1LL << 32)) return false;
+    return t.nrm_cur && t.pos_cur && t.gid_cur;
+}
+
+hipError_t launch_atrous_split_fused(const AtrousArgs &a, const TemporalArgs &t, hipStream_t s)
+{
+    if (!atrous_split_fused_supported(a, t)) return hipErrorInvalidValue;
+    LaneFused f;
+    memset(&f, 0, sizeof(f));
+    static_cast<TemporalArgs &>(f) = t;
+    return a.dst ? launch_lane_cfg<1, true, 1, 0, 4>(a, s, &f) : launch_lane_cfg<1, false, 1, 0, 4>(a, s, &f);
+}
+
 // step 2 with both y-phases in one workgroup, not fused (reads the accumulated plane like every other level)
 hipError_t launch_atrous_lane_2y(const AtrousArgs &a, hipStream_t s)
 {

@@ -146,6 +146,8 @@ struct LaneFused : TemporalArgs {
 //        3 fused PREPARE pass (non-temporal mode, reference EstimateVariance :320-329 + :370 and the G-buffer split): the loaders
 //          stage colour from the 1-spp input, variance = 10 and normal / position from the AoS texels, and write the split planes
 //          of the pixels the workgroup owns; standard geometry (one y-phase per workgroup), the pre-blur rows are the constant 10
+//        4 fused G-BUFFER SPLIT only (temporal frames): colour + variance come from the plane the temporal pass wrote, normal /
+//          position / geomId from the AoS texels; the loaders write the split planes the temporal pass then does not write
 template <int LOG2S, bool HASVAR, int LOG2P = LOG2S, int LOG2Y = 0, int FUSED = 0, int REUSE = 0>
 __global__ __launch_bounds__(NT) void k_atrous_lane(AtrousArgs a, LaneGeom gm, std::conditional_t<FUSED != 0, LaneFused, LaneNoTemporal> ta)
 {
@@ -155,7 +157,7 @@ __global__ __launch_bounds__(NT) void k_atrous_lane(AtrousArgs a, LaneGeom gm, s
     constexpr int YP = 1 << LOG2Y;               // y-phases held by one workgroup
     constexpr bool CHUNKED = (P < S);
     static_assert(YP == 1 || (YP == 2 && S == 2 && P == S), "two y-phases per workgroup: step 2 only");
-    constexpr bool TFUSED = (FUSED == 1 || FUSED == 2), PFUSED = (FUSED == 3);
+    constexpr bool TFUSED = (FUSED == 1 || FUSED == 2), PFUSED = (FUSED == 3 || FUSED == 4);      // PFUSED: the loaders read texels and write the split planes
     static_assert(!TFUSED || YP == 2, "the fused temporal pass needs the pre-blur rows in the ring");
     static_assert(!PFUSED || (YP == 1 && P == S), "the fused prepare pass uses the plain geometry of steps <= 8");
     constexpr int WPP = NWC / (P * YP);          // waves per x-phase (and y-phase)
@@ -263,9 +265,13 @@ __global__ __launch_bounds__(NT) void k_atrous_lane(AtrousArgs a, LaneGeom gm, s
     // is the constant of the non-temporal mode (:327), normal / position / geomId from the boundary's 52-byte texel
     auto stage_load = [&](Px &lp, unsigned q) {
         if constexpr (PFUSED) {
-            const float *c3 = reinterpret_cast<const float *>(reinterpret_cast<const char *>(ta.in_rgb) + q * 12u);
             const float *g = reinterpret_cast<const float *>(reinterpret_cast<const char *>(ta.gbuf) + q * 52u);
-            lp.cv = make_float4(c3[0], c3[1], c3[2], 10.0f);
+            if constexpr (FUSED == 3) {
+                const float *c3 = reinterpret_cast<const float *>(reinterpret_cast<const char *>(ta.in_rgb) + q * 12u);
+                lp.cv = make_float4(c3[0], c3[1], c3[2], 10.0f);
+            } else {
+                lp.cv = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(a.src) + q * 16u);
+            }
             lp.nx = g[0]; lp.ny = g[1]; lp.nz = g[2];
             lp.px = g[3]; lp.py = g[4]; lp.pz = g[5];
             lp.gid = __float_as_int(g[12]);
@@ -321,7 +327,7 @@ __global__ __launch_bounds__(NT) void k_atrous_lane(AtrousArgs a, LaneGeom gm, s
                     n[0] = px[m].nx; n[1] = px[m].ny; n[2] = px[m].nz;
                     p[0] = px[m].px; p[1] = px[m].py; p[2] = px[m].pz;
                     ta.gid_cur[q] = px[m].gid;
-                    if (ta.cv_acc) ta.cv_acc[q] = px[m].cv;        // only when something besides this level reads the plane
+                    if constexpr (FUSED == 3) { if (ta.cv_acc) ta.cv_acc[q] = px[m].cv; }       // only when something besides this level reads the plane
                 }
             }
         }
@@ -338,7 +344,7 @@ __global__ __launch_bounds__(NT) void k_atrous_lane(AtrousArgs a, LaneGeom gm, s
                 const int y = phase + (bo << LOG2S) + (d ? 1 : -1);
                 const int xs = x0 - 1 + xb;
                 if (y >= 0 && y < H && xs >= 0 && xs < W && bo < b1) {
-                    if constexpr (PFUSED) v[m] = 10.0f;         // the variance of every pixel in the non-temporal mode (:327)
+                    if constexpr (FUSED == 3) v[m] = 10.0f;     // the variance of every pixel in the non-temporal mode (:327)
                     else v[m] = *reinterpret_cast<const float *>(vbase + (unsigned)y * vys + (unsigned)xs * vxs);
                 }
             }
@@ -461,7 +467,7 @@ __global__ __launch_bounds__(NT) void k_atrous_lane(AtrousArgs a, LaneGeom gm, s
                 const unsigned rm = (unsigned)min(max(ym, 0), H - 1) * vys, rp = (unsigned)min(max(yp, 0), H - 1) * vys;
 #pragma unroll
                 for (int m = 0; m < MBL; m++)
-                    if constexpr (PFUSED) lbv[m] = 10.0f;
+                    if constexpr (FUSED == 3) lbv[m] = 10.0f;
                     else lbv[m] = *reinterpret_cast<const float *>(vbase + (b_d[m] ? rp : rm) + (unsigned)max(b_voff[m], 0));
             }
         }

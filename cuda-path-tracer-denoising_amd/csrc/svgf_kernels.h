@@ -115,6 +115,8 @@ struct TemporalArgs {
     void *dump;               // fused kernel only: >= 4 KB of scrap the stores of pixels a workgroup does not own go to
     const void *arena;        // fused kernel only: the ONE allocation all the context's planes (and dump) live in, and its size:
     size_t arena_bytes;       // the kernel addresses them as arena + 32-bit offset (svgf_atrous_lane_impl.h: LaneFused)
+    int skip_split;           // k_temporal on the AoS boundary: do not write nrm_cur / pos_cur / gid_cur (the first a-trous level's
+                              // loaders will: svgf_atrous_fused.hip, FUSED = 4)
 };
 
 hipError_t launch_temporal(const TemporalArgs &a, hipStream_t s, bool single_wave_blocks);
@@ -141,6 +143,9 @@ double     atrous_fused_estimate_us(const AtrousArgs &a, int n_cu);
 // non-temporal mode: the prepare pass (variance fill + G-buffer split) fused into the first level (step 2, AoS boundary)
 hipError_t launch_atrous_prepare_fused(const AtrousArgs &a, const TemporalArgs &t, hipStream_t s);
 bool       atrous_prepare_fused_supported(const AtrousArgs &a, const TemporalArgs &t);
+// temporal frames: the G-buffer split alone in the first level's loaders (the temporal pass then runs with skip_split)
+hipError_t launch_atrous_split_fused(const AtrousArgs &a, const TemporalArgs &t, hipStream_t s);
+bool       atrous_split_fused_supported(const AtrousArgs &a, const TemporalArgs &t);
 hipError_t launch_atrous_lane_2y(const AtrousArgs &a, hipStream_t s);  // step 2, both y-phases per workgroup, not fused (A/B)
 hipError_t launch_atrous_lattice(const AtrousArgs &a, hipStream_t s);  // lattice sub-images in LDS (steps >= 64)
 bool       atrous_lattice_supported(const AtrousArgs &a);

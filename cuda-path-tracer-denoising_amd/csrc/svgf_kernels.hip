@@ -59,9 +59,11 @@ __global__ __launch_bounds__(BLOCK) void k_temporal(TemporalArgs a)
         nx = t[0]; ny = t[1]; nz = t[2];
         px = t[3]; py = t[4]; pz = t[5];
         gid = __float_as_int(t[12]);
-        a.nrm_cur[3 * (size_t)p] = nx; a.nrm_cur[3 * (size_t)p + 1] = ny; a.nrm_cur[3 * (size_t)p + 2] = nz;
-        a.pos_cur[3 * (size_t)p] = px; a.pos_cur[3 * (size_t)p + 1] = py; a.pos_cur[3 * (size_t)p + 2] = pz;
-        a.gid_cur[p] = gid;
+        if (!a.skip_split) {
+            a.nrm_cur[3 * (size_t)p] = nx; a.nrm_cur[3 * (size_t)p + 1] = ny; a.nrm_cur[3 * (size_t)p + 2] = nz;
+            a.pos_cur[3 * (size_t)p] = px; a.pos_cur[3 * (size_t)p + 1] = py; a.pos_cur[3 * (size_t)p + 2] = pz;
+            a.gid_cur[p] = gid;
+        }
     } else {                  // planar path: the producer wrote the planes in place (svgf_planar_gbuffer), 28 B read, nothing split
         nx = a.nrm_cur[3 * (size_t)p]; ny = a.nrm_cur[3 * (size_t)p + 1]; nz = a.nrm_cur[3 * (size_t)p + 2];
         px = a.pos_cur[3 * (size_t)p]; py = a.pos_cur[3 * (size_t)p + 1]; pz = a.pos_cur[3 * (size_t)p + 2];
