@@ -1,0 +1,50 @@
+"""Randomised parity: sizes, parameter sets and mode switches drawn from a seeded generator, HIP (default kernel selection, so
+every frame takes whatever path the library picks: fused prepare pass, lane / strip / lattice / gather levels, debug views)
+against the CPU oracle on every frame.  60 sequences x 3 frames; the bar is the suite's: <= 1e-5 relative per channel value
+(<= 1e-4 once a sequence runs steps >= 64, whose lattice kernel sums in another order), history lengths bit for bit."""
+import numpy as np
+import pytest
+
+from conftest import relerr
+
+pytestmark = pytest.mark.gpu
+
+
+def _draw(rng):
+    W = int(rng.choice([int(rng.integers(1, 40)), int(rng.integers(40, 300)), int(rng.integers(300, 700))]))
+    H = int(rng.choice([int(rng.integers(1, 30)), int(rng.integers(30, 160))]))
+    nl = int(rng.integers(0, 8))
+    kw = dict(atrous_nlevel=nl, history_level=int(rng.integers(0, nl + 2)), paper_steps=int(rng.integers(0, 2)),
+              blur_variance=int(rng.integers(0, 2)), sepcolor=int(rng.integers(0, 2)), addcolor=int(rng.integers(0, 2)),
+              color_alpha=float(rng.choice([0.2, 0.05, 0.5, 1.0])), moment_alpha=float(rng.choice([0.2, 0.6, 1.0])),
+              sigma_l=float(rng.choice([0.45, 0.7, 1.5, 4.0])), sigma_n=float(rng.choice([0.2, 0.05, 1.0])),
+              sigma_x=float(rng.choice([0.35, 0.1, 2.0])))
+    return W, H, kw
+
+
+@pytest.mark.parametrize("block", range(6))
+def test_random_sequences_match_the_oracle(pkg, orc, block):
+    rng = np.random.default_rng(20260928 + block)
+    worst = 0.0
+    for case in range(10):
+        W, H, kw = _draw(rng)
+        moving = bool(rng.integers(0, 2))
+        d = pkg.Denoiser(W, H, 0)
+        o = orc.Oracle(pkg, W, H, threads=4)
+        big_steps = False
+        for f in range(3):
+            modes = dict(temporal_enable=int(rng.choice([1, 1, 1, 0])), spatial_enable=int(rng.choice([1, 1, 1, 0])),
+                         right_view_option=int(rng.choice([0, 0, 0, 0, 1, 2])))
+            p = pkg.reference_defaults().set(**kw, **modes)
+            step_max = 1 << (kw["atrous_nlevel"] - 1 if kw["paper_steps"] else kw["atrous_nlevel"]) if kw["atrous_nlevel"] else 0
+            big_steps = big_steps or step_max >= 64
+            c, g, cam = pkg.synth.render_frame(W, H, f, seed=int(rng.integers(1, 1 << 30)), moving=moving)
+            got = d.denoise_host(c, g, cam, p)
+            ref = o.denoise(c, g, cam, p)
+            e = float(relerr(got, ref).max())
+            worst = max(worst, e)
+            tol = 1e-4 if big_steps else 1e-5
+            assert e <= tol, f"block {block} case {case} {W}x{H} frame {f} {kw} {modes}: {e:.3e}"
+            assert np.array_equal(d.read_state(0), o.read_state(0)), f"block {block} case {case} {W}x{H} frame {f}: history length"
+        d.free(); o.free()
+    print(f"block {block}: worst relative error {worst:.3e}")
