@@ -1,5 +1,5 @@
-"""Randomised parity: sizes, parameter sets and mode switches drawn from a seeded generator, HIP (default kernel selection, so
-every frame takes whatever path the library picks: fused prepare pass, lane / strip / lattice / gather levels, debug views)
+"""Randomised parity: sizes, parameter sets and mode switches drawn from a seeded generator, HIP (kernel_variant 0 / 6 / 4 / 1, so
+the frames take every path the library has: fused temporal or prepare pass, lane / strip / lattice / gather levels, debug views)
 against the CPU oracle on every frame.  60 sequences x 3 frames; the bar is the suite's: <= 1e-5 relative per channel value
 (<= 1e-4 once a sequence runs steps >= 64, whose lattice kernel sums in another order), history lengths bit for bit."""
 import numpy as np
@@ -18,7 +18,10 @@ def _draw(rng):
               blur_variance=int(rng.integers(0, 2)), sepcolor=int(rng.integers(0, 2)), addcolor=int(rng.integers(0, 2)),
               color_alpha=float(rng.choice([0.2, 0.05, 0.5, 1.0])), moment_alpha=float(rng.choice([0.2, 0.6, 1.0])),
               sigma_l=float(rng.choice([0.45, 0.7, 1.5, 4.0])), sigma_n=float(rng.choice([0.2, 0.05, 1.0])),
-              sigma_x=float(rng.choice([0.35, 0.1, 2.0])))
+              sigma_x=float(rng.choice([0.35, 0.1, 2.0])),
+              # 0 the library's choice; 6 fuses whatever pass precedes the first level into it wherever that is possible
+              # (temporal pass: svgf_atrous_fused.hip FUSED 1; prepare pass: FUSED 3); 4 lane kernels with nothing fused; 1 gather
+              kernel_variant=int(rng.choice([0, 0, 6, 6, 4, 1])))
     return W, H, kw
 
 
