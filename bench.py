@@ -257,7 +257,7 @@ def main():
     out = torch.empty((H, W, 3), dtype=torch.float32, device=dev)
     den = pkg.Denoiser(W, H, device=local_rank)
     stream = torch.cuda.current_stream(dev)
-    PROFILE_STRIDE = 8      # an event pair attached to every kernel dispatch of every 8th timed step (a timed frame runs ~25 us longer)
+    PROFILE_STRIDE = 10     # an event pair attached to every kernel dispatch of every 10th timed step (a timed frame runs ~25 us longer)
     den.profile_stride(PROFILE_STRIDE)
     den.profile_enable(a.steps)
 
@@ -403,7 +403,7 @@ def main():
                          "kernel": "one plain a-trous level: k_atrous_lane (steps 4-32 when the first level is fused with the temporal pass, else 2-32; k_atrous_strip where the library's cost model prefers it); mean over those launches of a frame; the fused temporal + first-level launch is reported under kernels_us", "bytes_per_launch": ATROUS_BYTES_PER_PIXEL * W * H,
                          "mean_launch_us": round(a_ms * 1e3, 2), "launches_timed": len(atrous_ms),
                          "launch_includes_fused_prepare_pass": level_is_fused,
-                         "note": "everything ordered on one stream; durations are the dispatches' own begin / end timestamps (HIP events attached by hipExtLaunchKernelGGL on the launch stream, every 8th timed frame); 'isolated' repeats the measurement on every kernel of 16 frames",
+                         "note": "everything ordered on one stream; durations are the dispatches' own begin / end timestamps (HIP events attached by hipExtLaunchKernelGGL on the launch stream, every 10th timed frame); 'isolated' repeats the measurement on every kernel of 16 frames",
                          "isolated": {"mean_launch_us": round(iso_us, 2), "achieved": round(iso_gbs, 1),
                                       "frac": round(iso_gbs / HBM_PEAK_GBS, 4), "launches_timed": len(iso_atrous_ms)},
                          # the secondary limiter.  24 taps x (2 v_sqrt + 1 v_exp) + 5 (centre, normalisation) per pixel-level
