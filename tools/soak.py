@@ -3,7 +3,8 @@
 a synchronisation between calls, parameters redrawn every K frames (--random K).
   --pair default-fused (the default): context A runs the default path (temporal pass + lane kernels), context B forces the fused
         temporal + first-level kernel (kernel_variant 6; it falls back to the unfused path by itself for parameter draws it
-        does not support).  Outputs must agree to 1e-5 relative at every check, history lengths bit for bit.
+        does not support).  Outputs must agree to 1e-5 relative at every check (1e-4 while levels 6+ are on: steps >= 64), history
+        lengths bit for bit.
   --pair default-gather: B runs the strict gather kernel on every level (kernel_variant 1): <= 1e-5.
   --pair same: both default (since round 4 SvgfParams::inputs_ready is ignored, so this is the old overlap soak's shape):
         bit-identical.
@@ -66,11 +67,13 @@ def main():
                 den = torch.clamp(torch.abs(oa[f & 1]), min=1e-3)
                 err = float((torch.abs(oa[f & 1] - ob[f & 1]) / den).max())
                 worst = max(worst, err)
-                same = err <= 1e-5 and bool((da.read_state(0) == db.read_state(0)).all())
+                # steps >= 64 (levels 6+) run the lattice kernel, which sums in another order than the lane / gather kernels: the suite's 1e-4
+                tol = 1e-4 if pa.atrous_nlevel >= 6 else 1e-5
+                same = err <= tol and bool((da.read_state(0) == db.read_state(0)).all())
             fin = bool(torch.isfinite(oa[f & 1]).all())
             if not (same and fin):
                 bad += 1
-                print(f"frame {f}: agree={same} finite={fin} params nlevel={pa.atrous_nlevel} hist={pa.history_level} paper={pa.paper_steps} view={pa.right_view_option} t={pa.temporal_enable} s={pa.spatial_enable}")
+                print(f"frame {f}: agree={same} (max rel {err if a.pair != 'same' else 0.0:.2e}) finite={fin} params nlevel={pa.atrous_nlevel} hist={pa.history_level} paper={pa.paper_steps} view={pa.right_view_option} t={pa.temporal_enable} s={pa.spatial_enable}")
     torch.cuda.synchronize()
     print(f"soak {W}x{H}, {a.frames} frames, {a.pair}: " + (f"OK at every check (worst relative difference {worst:.2e}, history lengths identical)" if bad == 0 and a.pair != "same"
           else "OK, bit-identical at every check" if bad == 0 else str(bad) + " MISMATCHES"))
