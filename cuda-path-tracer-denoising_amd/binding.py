@@ -18,6 +18,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsvgf_hip.so")
+LIB_EXP_PATH = os.path.join(_HERE, "libsvgf_hip_exp.so")     # -DSVGF_BUILD_EXPERIMENTS: parked variants + tuning table (tests / tools only)
 
 SVGF_OK = 0
 STATE_HISTORY_LENGTH, STATE_MOMENTS, STATE_COLOR_HISTORY, STATE_VARIANCE_TEMPORAL, STATE_COLOR_ACC = range(5)
@@ -29,7 +30,8 @@ EXPORTS = ["svgf_version", "svgf_params_default", "svgf_create", "svgf_destroy",
            "svgf_denoise_host", "svgf_sync", "svgf_last_error", "svgf_width", "svgf_height", "svgf_read_state",
            "svgf_set_capture", "svgf_profile_enable", "svgf_profile_stride", "svgf_profile_frames", "svgf_profile_read",
            "svgf_synth_camera", "svgf_synth_render", "svgf_scene_render", "svgf_scene_render_mesh", "svgf_display_pack", "svgf_save_png",
-           "svgf_planar_gbuffer", "svgf_denoise_planar", "svgf_synth_render_planar", "svgf_params_sizeof", "svgf_scene_render_mesh_planar"]
+           "svgf_planar_gbuffer", "svgf_denoise_planar", "svgf_synth_render_planar", "svgf_params_sizeof", "svgf_scene_render_mesh_planar",
+           "svgf_sync_stream", "svgf_build_has_experiments"]
 
 
 class SvgfCamera(C.Structure):
@@ -86,11 +88,42 @@ class SvgfError(RuntimeError):
 
 
 _lib = None
+_lib_exp = None
+# tuning knobs of the experiments build that tools/experiments/*.sh pass as environment variables: forwarded to svgf_exp_set()
+# when the experiments library is loaded (the C library itself reads no environment variable)
+_EXP_ENV = {"SVGF_LANE_SEGROWS": "lane_segrows", "SVGF_LANE_DBG": "lane_dbg", "SVGF_LANE_DBG_SKIP": "lane_dbg_skip",
+            "SVGF_STRIP_SEGROWS": "strip_segrows", "SVGF_STRIP_FIXED_ROWS": "strip_fixed_rows", "SVGF_STRIP_TX": "strip_tx",
+            "SVGF_STRIP_ROWS": "strip_rows", "SVGF_STRIP_DBG": "strip_dbg", "SVGF_STRIP_DBG_SKIP": "strip_dbg_skip",
+            "SVGF_NO_VARIANCE_PLANE": "no_variance_plane", "SVGF_REUSE": "reuse", "SVGF_SPLIT_FUSED": "split_fused"}
 
 
-def load_library(path: str | None = None):
-    """Load libsvgf_hip.so and declare prototypes.  Fails loudly when the library is absent."""
-    global _lib
+def exp_set(name: str, value: int):
+    """svgf_exp_set of the experiments build (process-wide; read by svgf_create / the launchers of libsvgf_hip_exp.so)."""
+    lib = load_library(experiments=True)
+    if lib.svgf_exp_set(name.encode(), int(value)) != SVGF_OK:
+        raise SvgfError(f"svgf_exp_set({name!r}, {value}) failed")
+
+
+def exp_clear():
+    load_library(experiments=True).svgf_exp_clear()
+
+
+def load_library(path: str | None = None, experiments: bool = False):
+    """Load libsvgf_hip.so (or, experiments=True, libsvgf_hip_exp.so) and declare prototypes.  Fails loudly when the library is
+    absent.  SVGF_USE_EXPERIMENTS_LIB=1 in the environment makes the experiments build the default of this PYTHON binding
+    (tools/experiments/*.sh); the product path never sets it."""
+    global _lib, _lib_exp
+    if path is None and not experiments and os.environ.get("SVGF_USE_EXPERIMENTS_LIB"):
+        experiments = True
+    if path is None and experiments:
+        if _lib_exp is None:
+            _lib_exp = load_library(LIB_EXP_PATH)
+            _lib_exp.svgf_exp_set.argtypes = [C.c_char_p, C.c_int]
+            for env, key in _EXP_ENV.items():
+                if env in os.environ:
+                    v = os.environ[env]
+                    _lib_exp.svgf_exp_set(key.encode(), int(v) if v.lstrip("-").isdigit() else 1)
+        return _lib_exp
     if _lib is not None and path is None:
         return _lib
     path = path or LIB_PATH
@@ -115,6 +148,7 @@ def load_library(path: str | None = None):
     lib.svgf_denoise.argtypes = [vp, vp, vp, vp, C.POINTER(SvgfCamera), C.POINTER(SvgfParams), vp]
     lib.svgf_denoise_host.argtypes = [vp, vp, vp, vp, C.POINTER(SvgfCamera), C.POINTER(SvgfParams)]
     lib.svgf_sync.argtypes = [vp]
+    lib.svgf_sync_stream.argtypes = [vp, vp]
     lib.svgf_last_error.argtypes = [vp]
     lib.svgf_last_error.restype = C.c_char_p
     lib.svgf_width.argtypes = [vp]
@@ -163,8 +197,9 @@ def _ptr(x):
 class Denoiser:
     """One SVGF context on one GPU (denoiseInit .. denoiseFree of the reference, handle-based)."""
 
-    def __init__(self, width: int, height: int, device: int = 0):
-        self.lib = load_library()
+    def __init__(self, width: int, height: int, device: int = 0, experiments: bool = False):
+        """experiments=True: the context lives in libsvgf_hip_exp.so (kernel_variant 5 / 6, exp_set knobs) — tests and tools only."""
+        self.lib = load_library(experiments=experiments)
         self.width, self.height = int(width), int(height)
         self.ui = SvgfParams()
         self.lib.svgf_params_default(C.byref(self.ui))
@@ -230,6 +265,11 @@ class Denoiser:
 
     def sync(self):
         self._check(self.lib.svgf_sync(self.h), "svgf_sync")
+
+    def sync_stream(self, stream=None):
+        """Wait for what has been enqueued on `stream` only (svgf_sync waits for the whole device, as the reference does)."""
+        s = None if stream is None else (stream if isinstance(stream, int) else stream.cuda_stream)
+        self._check(self.lib.svgf_sync_stream(self.h, s), "svgf_sync_stream")
 
     def set_capture(self, on: bool = True):
         self._check(self.lib.svgf_set_capture(self.h, 1 if on else 0), "svgf_set_capture")

@@ -1,4 +1,5 @@
-"""Build recipes (no cmake, no JIT cache): everything lands in-tree so it travels to the GPU box."""
+"""Build recipe of the product library (no cmake, no JIT cache): everything lands in-tree so it travels to the GPU box.
+The checkers (CPU restatement, the reference's own denoise.cu) have their own recipe outside this package."""
 from __future__ import annotations
 
 import os
@@ -9,10 +10,12 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(_HERE)
 CSRC = os.path.join(_HERE, "csrc")
 LIB = os.path.join(_HERE, "libsvgf_hip.so")
-ORACLE_DIR = os.path.join(ROOT, "oracle")
-ORACLE_LIB = os.path.join(ORACLE_DIR, "libsvgf_oracle.so")
+# The experiments build (-DSVGF_BUILD_EXPERIMENTS): the product's sources + the parked kernel variants and the tuning table
+# (svgf_exp_set).  Test / tools infrastructure: nothing on the product path loads it (binding.load_library(experiments=True) does).
+LIB_EXP = os.path.join(_HERE, "libsvgf_hip_exp.so")
 
-HIP_SOURCES = ["svgf_api.hip", "svgf_kernels.hip", "svgf_atrous_strip.hip", "svgf_atrous_lane.hip", "svgf_atrous_lane_reuse.hip", "svgf_atrous_fused.hip", "svgf_atrous_lattice.hip", "svgf_synth.hip", "svgf_scene.hip", "svgf_display.hip"]
+HIP_SOURCES = ["svgf_api.hip", "svgf_kernels.hip", "svgf_atrous_strip.hip", "svgf_atrous_lane.hip", "svgf_atrous_prepare_fused.hip", "svgf_atrous_lattice.hip", "svgf_synth.hip", "svgf_scene.hip", "svgf_display.hip"]
+HIP_SOURCES_EXPERIMENTS = ["svgf_atrous_lane_reuse.hip", "svgf_atrous_fused.hip"]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-function"]
 # Per-file flags.  svgf_atrous_fused.hip: SimplifyCFG's common-code sinking merges the last store of the "bilinear history" branch
 # with the last store of the "fallback consistency data" branch of the temporal stage into ONE store through a phi of two
@@ -41,14 +44,19 @@ def hipcc_path() -> str:
     return p
 
 
-def build_hip(force: bool = False) -> str:
-    """Compile the HIP kernels + C ABI for gfx950 into cuda-path-tracer-denoising_amd/libsvgf_hip.so."""
-    srcs = [os.path.join(CSRC, s) for s in HIP_SOURCES]
-    deps = srcs + [os.path.join(CSRC, h) for h in ("svgf_kernels.h", "svgf_temporal.h", "svgf_atrous_lane_impl.h")] + [os.path.join(ROOT, "include", "svgf.h")]
+def build_hip(force: bool = False, experiments: bool = False) -> str:
+    """Compile the HIP kernels + C ABI for gfx950 into cuda-path-tracer-denoising_amd/libsvgf_hip.so (the product), or, with
+    experiments=True, into libsvgf_hip_exp.so (-DSVGF_BUILD_EXPERIMENTS: parked kernel variants 5 / 6, cross-level term reuse, the
+    tuning table behind svgf_exp_set; what tools/experiments/ and the tests marked `experiments` load)."""
+    LIB = LIB_EXP if experiments else globals()["LIB"]
+    srcs = [os.path.join(CSRC, s) for s in HIP_SOURCES + (HIP_SOURCES_EXPERIMENTS if experiments else [])]
+    deps = srcs + [os.path.join(CSRC, h) for h in ("svgf_kernels.h", "svgf_temporal.h", "svgf_atrous_lane_impl.h", "svgf_atrous_lane_tfused.inc.h")] + [os.path.join(ROOT, "include", "svgf.h")]
     if not force and _newer(LIB, deps):
         return LIB
     tmp = LIB + f".tmp{os.getpid()}"
-    extra = os.environ.get("SVGF_EXTRA_HIPCC_FLAGS", "").split()      # kernel experiments only (tools/, profiles/)
+    extra = os.environ.get("SVGF_EXTRA_HIPCC_FLAGS", "").split() if experiments else []      # -D switches of tools/experiments/ (experiments build only)
+    if experiments:
+        extra = ["-DSVGF_BUILD_EXPERIMENTS"] + extra
     # one hipcc -c per translation unit, in parallel (the a-trous kernels are template-heavy: ~70 s serial, ~30 s so),
     # objects in a scratch directory, then one link
     import concurrent.futures
@@ -62,32 +70,3 @@ def build_hip(force: bool = False) -> str:
         _run([hipcc_path(), "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", tmp])
     os.replace(tmp, LIB)              # atomic: concurrent ranks never see a half-written library
     return LIB
-
-
-def build_oracle(force: bool = False) -> str:
-    """Compile the CPU oracle (test infrastructure) into oracle/libsvgf_oracle.so."""
-    src = os.path.join(ORACLE_DIR, "svgf_oracle.c")
-    deps = [src, os.path.join(ORACLE_DIR, "svgf_oracle.h"), os.path.join(ROOT, "include", "svgf.h")]
-    if not force and _newer(ORACLE_LIB, deps):
-        return ORACLE_LIB
-    tmp = ORACLE_LIB + f".tmp{os.getpid()}"
-    _run(["gcc", "-O2", "-ffp-contract=off", "-fopenmp", "-shared", "-fPIC", "-std=c11", "-Wall", src, "-o", tmp, "-lm"])
-    os.replace(tmp, ORACLE_LIB)
-    return ORACLE_LIB
-
-
-def build_reference(force: bool = False) -> str | None:
-    """Build the reference's own denoise.cu for gfx950 into oracle/_ref/ (only where /root/reference exists)."""
-    if not os.path.isdir("/root/reference/src"):
-        return None
-    out = os.path.join(ORACLE_DIR, "_ref", "ref_denoise_gpu")
-    mk = os.path.join(ORACLE_DIR, "ref", "Makefile")
-    if not os.path.exists(mk):
-        return None
-    if force and os.path.exists(out):
-        os.remove(out)
-    _run(["make", "-s", "-C", os.path.join(ORACLE_DIR, "ref")])       # raises with make's output when the recipe fails
-    scenes = os.path.join(ORACLE_DIR, "_ref", "scenes")
-    if not os.path.exists(out) or not os.path.isdir(scenes):
-        raise RuntimeError(f"reference build: make succeeded but {out} or {scenes} is missing")
-    return out

@@ -16,15 +16,17 @@
 #include "svgf_kernels.h"
 
 #define SVGF_MAX_KERNELS_PER_FRAME (SVGF_MAX_LEVELS + 4)
+// the prepare pass of the non-temporal mode fused into the first level (svgf_atrous_prepare_fused.hip, FUSED = 3): on by default
+// where the first level runs the lane kernel anyway (measured: profiles/r04_exp_prepare_fused.log)
+static const bool kPrepareFusedByDefault = true;
+#ifdef SVGF_BUILD_EXPERIMENTS
 // a row of the fused temporal + first-level kernel against a row of the plain lane kernel, as measured at 1920x1080 (DESIGN.md
 // 5.8, profiles/r04_exp_fused_*.log: 176 us in its last version against 42.7 for the plain level, i.e. the fused kernel LOSES to
 // temporal pass + level, 55 + 46 us): with this factor the automatic choice never fuses; kernel_variant 6 forces it
 static const double kFusedRowFactor = 4.1;
-// the prepare pass of the non-temporal mode fused into the first level (svgf_atrous_fused.hip, FUSED = 3): on by default where the
-// first level runs the lane kernel anyway (measured: profiles/r04_exp_prepare_fused.log)
-static const bool kPrepareFusedByDefault = true;
-// temporal frames: only the G-buffer split fused into the first level (FUSED = 4); default decided by measurement
+// temporal frames: only the G-buffer split fused into the first level (FUSED = 4); a measured loss, off unless svgf_exp_set("split_fused", 1)
 static const bool kSplitFusedByDefault = false;
+#endif
 
 struct svgf_ctx {
     int device, W, H;
@@ -32,14 +34,14 @@ struct svgf_ctx {
     float4 *cv[3];         // colour + variance planes: history, source, destination of a level (roles rotate)
     float *vp[3];          // zero-margined (W+2) x (H+2) copies of cv[k].w: what the step-16/32 levels take their 3x3 variance pre-blur from
     unsigned vp_valid;     // bit k: vp[k] holds the variance of cv[k]
-    int use_vplane;        // 0 only for A/B measurements (environment SVGF_NO_VARIANCE_PLANE at svgf_create)
+    int use_vplane;        // 0 only for A/B measurements (experiments build: svgf_exp_set("no_variance_plane", 1) before svgf_create)
     void *dump;            // 4 KB of scrap for the fused kernel (TemporalArgs::dump)
     char *arena;           // the one allocation cv[], nrm[], gid[], mom[], hlen[], pos[] and dump are carved from
     size_t arena_bytes;
     float4 *tp[2];         // cross-level reuse of the geometric terms: four terms per pixel, written by level L for level L+1 (lane kernels
-                           // only, svgf_atrous_lane_reuse.hip); allocated when a frame first has two consecutive lane-kernel levels
-    int use_split_fused;   // temporal frames: the G-buffer split in the first level's loaders (environment SVGF_SPLIT_FUSED=0/1 overrides the default)
-    int use_reuse;         // 1 only for A/B measurements (environment SVGF_REUSE at svgf_create): measured a loss, profiles/r04_ab_reuse_*.log
+                           // only, svgf_atrous_lane_reuse.hip; experiments build); allocated by svgf_create when use_reuse is set
+    int use_split_fused;   // experiments build, svgf_exp_set("split_fused", 1): the G-buffer split of temporal frames in the first level's loaders
+    int use_reuse;         // experiments build, svgf_exp_set("reuse", 1) before svgf_create: measured a loss, profiles/r04_ab_reuse_*.log
     int n_cu;              // compute units of the context's device (launch-geometry cost model of the kernel choice)
     signed char lane_cheaper[8];   // per log2(step): -1 not evaluated yet, 1 the lane kernel's estimate is the lower one
     signed char fuse_pays;         // -1 not evaluated yet, 1: the fused temporal + first-level kernel is the cheaper way through both
@@ -118,7 +120,44 @@ static void view_matrix_from_camera(const SvgfCamera *cam, float *out)
     for (int k = 0; k < 16; k++) out[k] = inv[k] * rdet;
 }
 
+#ifdef SVGF_BUILD_EXPERIMENTS
+// ---- tuning table of the experiments build (libsvgf_hip_exp.so): name -> int, process-wide.  The product build has neither the
+// table nor the entry point: SVGF_TUNE() is its default there and no environment variable is read anywhere in the library. ----
+namespace {
+struct ExpEntry { char name[32]; int value; };
+ExpEntry g_exp[64];
+int g_exp_n = 0;
+std::mutex g_exp_mu;
+}  // namespace
+int svgf_exp_get(const char *name, int dflt)
+{
+    std::lock_guard<std::mutex> lk(g_exp_mu);
+    for (int k = 0; k < g_exp_n; k++) if (!strcmp(g_exp[k].name, name)) return g_exp[k].value;
+    return dflt;
+}
+extern "C" int svgf_exp_set(const char *name, int value)
+{
+    if (!name || strlen(name) >= sizeof(g_exp[0].name)) return SVGF_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(g_exp_mu);
+    for (int k = 0; k < g_exp_n; k++) if (!strcmp(g_exp[k].name, name)) { g_exp[k].value = value; return SVGF_OK; }
+    if (g_exp_n >= 64) return SVGF_ERR_OOM;
+    strcpy(g_exp[g_exp_n].name, name);
+    g_exp[g_exp_n++].value = value;
+    return SVGF_OK;
+}
+extern "C" int svgf_exp_clear(void) { std::lock_guard<std::mutex> lk(g_exp_mu); g_exp_n = 0; return SVGF_OK; }
+#endif
+
 extern "C" int svgf_version(void) { return (SVGF_VERSION_MAJOR << 16) | SVGF_VERSION_MINOR; }
+// 1: this library was built with -DSVGF_BUILD_EXPERIMENTS (parked kernel variants 5 / 6, tuning table); the product build says 0
+extern "C" int svgf_build_has_experiments(void)
+{
+#ifdef SVGF_BUILD_EXPERIMENTS
+    return 1;
+#else
+    return 0;
+#endif
+}
 extern "C" int svgf_params_sizeof(void) { return (int)sizeof(SvgfParams); }
 
 extern "C" int svgf_params_default(SvgfParams *p)
@@ -180,6 +219,9 @@ static int zero_state(svgf_ctx *c)
     // gcur is deliberately NOT reset: the pointers svgf_planar_gbuffer handed out (planes 1 - gcur) stay the ones the next
     // frame reads, so planar_gbuffer() -> reset() -> producer -> denoise_planar() works (both plane sets are zero again)
     c->hist = 0; c->acc = 0; c->cur = 0;
+    // The clears above run on the legacy stream; a caller may enqueue the next svgf_denoise on a non-blocking stream that does not
+    // order itself behind them: they are complete before svgf_create / svgf_reset return.
+    HIPC(c, hipStreamSynchronize(nullptr));
     return SVGF_OK;
 }
 
@@ -208,9 +250,11 @@ extern "C" int svgf_create(int device, int width, int height, svgf_ctx **out)
     memset(c, 0, sizeof(*c));
     c->device = device; c->W = width; c->H = height; c->n = (size_t)width * height;
     for (int k = 0; k < 16; k++) c->view_prev[k] = (k % 5 == 0) ? 1.0f : 0.0f;
-    c->use_vplane = getenv("SVGF_NO_VARIANCE_PLANE") ? 0 : 1;
-    c->use_reuse = getenv("SVGF_REUSE") ? 1 : 0;
-    { const char *e = getenv("SVGF_SPLIT_FUSED"); c->use_split_fused = e ? (atoi(e) != 0) : kSplitFusedByDefault; }
+    c->use_vplane = SVGF_TUNE("no_variance_plane", 0) ? 0 : 1;
+#ifdef SVGF_BUILD_EXPERIMENTS
+    c->use_reuse = SVGF_TUNE("reuse", 0) ? 1 : 0;
+    c->use_split_fused = SVGF_TUNE("split_fused", kSplitFusedByDefault ? 1 : 0) ? 1 : 0;
+#endif
     if (hipDeviceGetAttribute(&c->n_cu, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || c->n_cu < 8) c->n_cu = 256;
     memset(c->lane_cheaper, -1, sizeof(c->lane_cheaper));
     c->fuse_pays = -1;
@@ -236,6 +280,8 @@ extern "C" int svgf_create(int device, int width, int height, svgf_ctx **out)
     }
     // (+64 bytes: the step-16/32 lane kernel reads the variance plane in 16-byte pieces that may end 8 bytes behind the last margin)
     for (int k = 0; k < 3 && ok; k++) ok = hipMalloc((void **)&c->vp[k], (size_t)(width + 2) * (height + 2) * sizeof(float) + 64) == hipSuccess;
+    // (the terms planes of the parked cross-level reuse: allocated here, never in the middle of a frame)
+    for (int k = 0; k < 2 && ok && c->use_reuse; k++) ok = hipMalloc((void **)&c->tp[k], (size_t)(width + 64) * height * sizeof(float4)) == hipSuccess;
     if (!ok) {
         snprintf(g_create_err, sizeof(g_create_err), "svgf_create: hipMalloc failed for %dx%d", width, height);
         free_all(c); delete c;
@@ -275,6 +321,16 @@ extern "C" int svgf_sync(svgf_ctx *c)
     SvgfDeviceGuard dev_guard(c->device);
     if (!dev_guard.ok) { snprintf(c->err, sizeof(c->err), "hipSetDevice(%d) failed", c->device); return SVGF_ERR_HIP; }
     HIPC(c, hipDeviceSynchronize());
+    return SVGF_OK;
+}
+
+// Stream-scoped completion: wait for what has been enqueued on `stream` (this context's frames included) and nothing else.
+extern "C" int svgf_sync_stream(svgf_ctx *c, void *stream)
+{
+    if (!c) return SVGF_ERR_INVALID_ARG;
+    SvgfDeviceGuard dev_guard(c->device);
+    if (!dev_guard.ok) { snprintf(c->err, sizeof(c->err), "hipSetDevice(%d) failed", c->device); return SVGF_ERR_HIP; }
+    HIPC(c, hipStreamSynchronize((hipStream_t)stream));
     return SVGF_OK;
 }
 
@@ -423,6 +479,7 @@ static bool lane_pays(svgf_ctx *c, const AtrousArgs &a)
     return c->lane_cheaper[l] != 0;
 }
 
+#ifdef SVGF_BUILD_EXPERIMENTS
 // Temporal pass + first level as ONE kernel (svgf_atrous_fused.hip), or as two?  The fused kernel works on 240-column strips
 // with both y-phases of a strip in one workgroup and pays the same rounds x (rows + 6) launch geometry as the lane kernel; what
 // it saves is the temporal kernel (HBM-bound, 25.6 ns per kilopixel at 1080p) and 56 B/px of traffic between the two.  It runs
@@ -438,6 +495,7 @@ static bool fuse_pays(svgf_ctx *c, const AtrousArgs &a)
     }
     return c->fuse_pays != 0;
 }
+#endif
 
 // gbuffer_dev == nullptr: the planar path (svgf_denoise_planar) — the current-frame planes nrm/pos/gid[1 - gcur] (and `albedo`)
 // were filled in place by the producer
@@ -458,6 +516,13 @@ static int denoise_frame(svgf_ctx *c, void *out_rgb_dev, const void *in_rgb_dev,
                  : "svgf_denoise: kernel_variant %d unknown", p->kernel_variant);
         return SVGF_ERR_INVALID_ARG;
     }
+#ifndef SVGF_BUILD_EXPERIMENTS
+    if (p->kernel_variant == 5 || p->kernel_variant == 6) {
+        snprintf(c->err, sizeof(c->err), "svgf_denoise: kernel_variant %d is a parked experiment (two-y-phase geometry / temporal pass fused into "
+                 "the first level) and is not part of this build; build libsvgf_hip_exp.so (-DSVGF_BUILD_EXPERIMENTS)", p->kernel_variant);
+        return SVGF_ERR_UNSUPPORTED;
+    }
+#endif
     // every level is validated before anything is enqueued or any context state changes: a failure half-way through the
     // cascade would leave the colour history of this frame next to the G-buffer / moments of the previous one
     if (p->kernel_variant == 2 && p->spatial_enable && p->right_view_option != 1 && p->right_view_option != 2) {
@@ -510,6 +575,7 @@ static int denoise_frame(svgf_ctx *c, void *out_rgb_dev, const void *in_rgb_dev,
         t.reproj_sx = p->reproj_scale[0]; t.reproj_sy = p->reproj_scale[1];
         t.pos_prev = c->pos[c->gcur]; t.pos_tol = p->reproj_position_tol;
         t.dump = c->dump; t.arena = c->arena; t.arena_bytes = c->arena_bytes;
+#ifdef SVGF_BUILD_EXPERIMENTS      // parked: the temporal pass (or only its G-buffer split) in the first level's loaders, DESIGN.md 5.8
         if (cascade && (p->kernel_variant == 0 || p->kernel_variant == 6) && !p->paper_steps && p->spatial_variance_frames <= 0) {
             AtrousArgs probe;
             memset(&probe, 0, sizeof(probe));
@@ -524,6 +590,7 @@ static int denoise_frame(svgf_ctx *c, void *out_rgb_dev, const void *in_rgb_dev,
             probe.W = c->W; probe.H = c->H; probe.step = 2; probe.src = c->cv[acc];
             split_fused = atrous_split_fused_supported(probe, t) && atrous_strip_supported(probe) && atrous_lane_supported(probe) && lane_pays(c, probe);
         }
+#endif
         t.skip_split = split_fused ? 1 : 0;
         if (!fused) {
             LAUNCH(SVGF_KERNEL_TEMPORAL, launch_temporal(t, s, false));
@@ -591,7 +658,9 @@ static int denoise_frame(svgf_ctx *c, void *out_rgb_dev, const void *in_rgb_dev,
             }
             enum { K_FUSED, K_LANE, K_LANE2Y, K_STRIP, K_LATTICE, K_GATHER } which;
             if (fuse_here) which = K_FUSED;
+#ifdef SVGF_BUILD_EXPERIMENTS
             else if (strip && a.step == 2 && p->kernel_variant == 5 && atrous_lane_supported(a)) which = K_LANE2Y;
+#endif
             else if (strip && atrous_lane_supported(a) && (p->kernel_variant >= 4 || (p->kernel_variant == 0 && lane_pays(c, a)))) which = K_LANE;
             else if (strip) which = K_STRIP;
             else if (lattice) which = K_LATTICE;
@@ -608,10 +677,11 @@ static int denoise_frame(svgf_ctx *c, void *out_rgb_dev, const void *in_rgb_dev,
                 if (dst >= 0 && !last && a.step >= 8) a.var_dst = c->vp[dst];
             }
             if (dst >= 0) { if (a.var_dst) c->vp_valid |= 1u << dst; else c->vp_valid &= ~(1u << dst); }
+            int terms_out = -1;
+#ifdef SVGF_BUILD_EXPERIMENTS
             // Cross-level reuse of the geometric terms (svgf_atrous_lane_reuse.hip): a lane-kernel level reads the four terms the
             // previous lane-kernel level stored for it (its step is twice that level's), and stores four for the next level if that
             // one will run the lane kernel at twice this step.
-            int terms_out = -1;
             if (which == K_LANE && c->use_reuse) {
                 if (prev_terms >= 0 && a.step == 2 * prev_step) { a.tin = c->tp[prev_terms]; a.t_m = (c->W + a.step - 1) / a.step; }
                 if (!last && 2 * a.step <= 32) {
@@ -622,11 +692,11 @@ static int denoise_frame(svgf_ctx *c, void *out_rgb_dev, const void *in_rgb_dev,
                                            (p->kernel_variant >= 4 || (p->kernel_variant == 0 && lane_pays(c, nx)));
                     if (next_lane) {
                         terms_out = (prev_terms == 0) ? 1 : 0;
-                        if (!c->tp[terms_out]) HIPC(c, hipMalloc((void **)&c->tp[terms_out], (size_t)(c->W + 64) * c->H * sizeof(float4)));
                         a.tout = c->tp[terms_out]; a.t_m_out = (c->W + nx.step - 1) / nx.step;
                     }
                 }
             }
+#endif
             prev_terms = terms_out; prev_step = a.step;
             if (split_fused && level == 1 && which != K_LANE) {      // (the decision above and the kernel choice here use the same model)
                 snprintf(c->err, sizeof(c->err), "svgf_denoise: internal error, the G-buffer split was left to a first level that does not run the lane kernel");
@@ -637,15 +707,23 @@ static int denoise_frame(svgf_ctx *c, void *out_rgb_dev, const void *in_rgb_dev,
                 // the accumulated plane itself is only written when something besides this level reads it: a later frame (the
                 // history is not this level's output) or a test (svgf_set_capture)
                 t.cv_acc = (!keep || c->capture) ? c->cv[acc] : nullptr;
+#ifdef SVGF_BUILD_EXPERIMENTS
                 if (p->temporal_enable) LAUNCH(SVGF_KERNEL_FUSED, launch_atrous_fused(a, t, s));
-                else LAUNCH(SVGF_KERNEL_FUSED, launch_atrous_prepare_fused(a, t, s));
+                else
+#endif
+                LAUNCH(SVGF_KERNEL_FUSED, launch_atrous_prepare_fused(a, t, s));
                 if (c->capture) { HIPC(c, hipMemcpyAsync(c->cv_capture, c->cv[acc], c->n * sizeof(float4), hipMemcpyDeviceToDevice, s)); }
                 break;
-            case K_LANE:
-                if (split_fused && level == 1) LAUNCH(SVGF_KERNEL_ATROUS, launch_atrous_split_fused(a, t, s));
-                else LAUNCH(SVGF_KERNEL_ATROUS, launch_atrous_lane(a, s));
-                break;     // steps 2 .. 32: symmetric terms evaluated once
+            case K_LANE:       // steps 2 .. 32: symmetric terms evaluated once
+#ifdef SVGF_BUILD_EXPERIMENTS
+                if (split_fused && level == 1) { LAUNCH(SVGF_KERNEL_ATROUS, launch_atrous_split_fused(a, t, s)); break; }
+                if (a.tin || a.tout) { LAUNCH(SVGF_KERNEL_ATROUS, launch_atrous_lane_reuse(a, s)); break; }
+#endif
+                LAUNCH(SVGF_KERNEL_ATROUS, launch_atrous_lane(a, s));
+                break;
+#ifdef SVGF_BUILD_EXPERIMENTS
             case K_LANE2Y:  LAUNCH(SVGF_KERNEL_ATROUS, launch_atrous_lane_2y(a, s)); break;  // A/B partner of the fused kernel's geometry
+#endif
             case K_STRIP:   LAUNCH(SVGF_KERNEL_ATROUS, launch_atrous_strip(a, s)); break;
             case K_LATTICE: LAUNCH(SVGF_KERNEL_ATROUS, launch_atrous_lattice(a, s)); break;
             default:        LAUNCH(SVGF_KERNEL_ATROUS, launch_atrous_gather(a, s)); break;

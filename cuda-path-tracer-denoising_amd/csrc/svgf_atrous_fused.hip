@@ -1,4 +1,6 @@
-// svgf_atrous_fused.hip — the temporal pass fused into the first a-trous level (round 4).
+// svgf_atrous_fused.hip — EXPERIMENTS build only (libsvgf_hip_exp.so): the temporal pass fused into the first a-trous level
+// (round 4; DESIGN.md 5.8: parity-green, 176 us against 97 us for the two kernels it replaces — parked), the G-buffer split alone in the
+// first level's loaders (FUSED = 4, parked) and the two-y-phase geometry without fusion (kernel_variant 5).
 //
 // The temporal pass (reference BackProjection, src/denoise.cu:185-317, launched :362-367) is HBM- and latency-bound with the
 // VALU mostly idle; the a-trous level that follows it (src/denoise.cu:77-170, first iteration of the loop :386-392) is
@@ -15,6 +17,9 @@
 // geometry costs from what the fusion brings.
 #include <cstring>
 
+#ifndef SVGF_BUILD_EXPERIMENTS
+#error "svgf_atrous_fused.hip holds parked experiments: compile it with -DSVGF_BUILD_EXPERIMENTS (build.py: build_hip(experiments=True))"
+#endif
 #include "svgf_atrous_lane_impl.h"
 
 // byte offset of a context plane from the context's allocation; false when it does not fit 32 bits
@@ -73,26 +78,6 @@ hipError_t launch_atrous_fused(const AtrousArgs &a, const TemporalArgs &t, hipSt
     if (!t.dump || !fused_offsets(t, &f)) return hipErrorInvalidValue;
     if (t.gbuf) return a.dst ? launch_lane_cfg<1, true, 1, 1, 1>(a, s, &f) : launch_lane_cfg<1, false, 1, 1, 1>(a, s, &f);
     return a.dst ? launch_lane_cfg<1, true, 1, 1, 2>(a, s, &f) : launch_lane_cfg<1, false, 1, 1, 2>(a, s, &f);
-}
-
-// Non-temporal mode (reference EstimateVariance :320-329 + colour copy :370, and the G-buffer split of this library's prepare
-// kernel) fused into the first level: FUSED = 3 of the lane kernel.  Unlike the temporal pass this is loads and stores only — the
-// loaders fetch the 1-spp colour and the texel instead of three planes and write the split planes of the pixels their workgroup
-// owns — so it fits the loader waves: one launch and 108 B/px of traffic less per frame.
-bool atrous_prepare_fused_supported(const AtrousArgs &a, const TemporalArgs &t)
-{
-    if (a.step != 2 || !t.gbuf || !t.in_rgb) return false;          // the AoS boundary, the reference's first level
-    if ((long long)a.W * a.H * 52 >= (1LL << 32)) return false;      // 32-bit byte offsets into the texel array
-    return t.nrm_cur && t.pos_cur && t.gid_cur;
-}
-
-hipError_t launch_atrous_prepare_fused(const AtrousArgs &a, const TemporalArgs &t, hipStream_t s)
-{
-    if (!atrous_prepare_fused_supported(a, t)) return hipErrorInvalidValue;
-    LaneFused f;
-    memset(&f, 0, sizeof(f));
-    static_cast<TemporalArgs &>(f) = t;
-    return a.dst ? launch_lane_cfg<1, true, 1, 0, 3>(a, s, &f) : launch_lane_cfg<1, false, 1, 0, 3>(a, s, &f);
 }
 
 // Temporal frames on the AoS boundary: only the G-buffer SPLIT moves into the first level's loaders (FUSED = 4).  The temporal

@@ -23,7 +23,7 @@ bool atrous_lane_supported(const AtrousArgs &a)
 
 hipError_t launch_atrous_lane(const AtrousArgs &a, hipStream_t s)
 {
-    if (a.tin || a.tout) return launch_atrous_lane_reuse(a, s);       // cross-level reuse of the geometric terms: svgf_atrous_lane_reuse.hip
+    if (a.tin || a.tout) return hipErrorInvalidValue;                 // cross-level reuse of the geometric terms: svgf_atrous_lane_reuse.hip (experiments build)
     switch (a.step) {
     case 1: return a.dst ? launch_lane_cfg<0, true>(a, s) : launch_lane_cfg<0, false>(a, s);
     case 2: return a.dst ? launch_lane_cfg<1, true>(a, s) : launch_lane_cfg<1, false>(a, s);

@@ -7,6 +7,9 @@
 // G-buffer only.  A level that has a lane-kernel successor stores those four terms per pixel (16 B/px written), the successor
 // reads them (16 B/px read) and skips four of its twelve evaluations: 8 of 24 v_sqrt, 24 of 72 packed and 8 of 24 plain VALU
 // instructions and 4 of ~48 ds_read_b128 per pixel, on a kernel that is bound by instruction issue and leaves HBM half idle.
+#ifndef SVGF_BUILD_EXPERIMENTS
+#error "svgf_atrous_lane_reuse.hip is a parked experiment: compile it with -DSVGF_BUILD_EXPERIMENTS (build.py: build_hip(experiments=True))"
+#endif
 #include "svgf_atrous_lane_impl.h"
 
 namespace {

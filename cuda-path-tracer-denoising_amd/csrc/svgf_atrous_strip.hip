@@ -72,7 +72,7 @@ struct StripGeom {
     int seg_rows;   // lattice rows per segment
     int n_groups;   // S * n_segs
     float kn, kx;   // log2(e) / (sigma_n + 1e-6), log2(e) / (sigma_x + 1e-6)
-    unsigned long long *dbg;   // tuning only (SVGF_STRIP_DBG): per-phase s_memtime stamps of one workgroup
+    unsigned long long *dbg;   // tuning only (experiments build, svgf_exp_set("strip_dbg", <block>)): per-phase s_memtime stamps of one workgroup
     int dbg_block;
 };
 
@@ -654,7 +654,7 @@ long strip_segment_search(int n_strips, int S, int nb_max, int ROWS, int capacit
 {
     int best_L = nb_max;
     long best_cost = -1;
-    static const int fixed_rows = getenv("SVGF_STRIP_FIXED_ROWS") ? atoi(getenv("SVGF_STRIP_FIXED_ROWS")) : 8;   // tuning only
+    static const int fixed_rows = SVGF_TUNE("strip_fixed_rows", 8);   // tuning only
     for (int L = ROWS * 4; L <= nb_max + ROWS; L++) {        // L need not be a multiple of ROWS: the last iteration idles rows
         const int segs_l = (nb_max + L - 1) / L;
         // (phase, segment) groups are dealt round-robin to the 8 XCDs (blockIdx % 8), all strips of a group to the same
@@ -691,17 +691,18 @@ hipError_t launch_cfg(const AtrousArgs &a, hipStream_t s)
     const int capacity = n_cu * bpc;
     int best_L = nb_max;
     (void)strip_segment_search(gm.n_strips, S, nb_max, ROWS, capacity, &best_L);
-    if (const char *e = getenv("SVGF_STRIP_SEGROWS")) { int v = atoi(e); if (v > 0) best_L = v; }
+    if (const int v = SVGF_TUNE("strip_segrows", 0); v > 0) best_L = v;
     gm.seg_rows = best_L;
     gm.n_segs = (nb_max + best_L - 1) / best_L;
     gm.n_groups = S * gm.n_segs;
     gm.dbg = nullptr; gm.dbg_block = 0;
     static unsigned long long *dbg_buf = nullptr;
-    const char *dbg_env = getenv("SVGF_STRIP_DBG");
+    const int dbg_block = SVGF_TUNE("strip_dbg", -1);
+    const bool dbg_env = dbg_block >= 0;
     if (dbg_env) {
         if (!dbg_buf) (void)hipMalloc((void **)&dbg_buf, 16 * 16 * 8 * sizeof(unsigned long long));
         (void)hipMemsetAsync(dbg_buf, 0, 16 * 16 * 8 * sizeof(unsigned long long), s);
-        gm.dbg = dbg_buf; gm.dbg_block = atoi(dbg_env);
+        gm.dbg = dbg_buf; gm.dbg_block = dbg_block;
     }
     gm.kn = (float)(1.4426950408889634 / ((double)a.sigma_n + 1e-6));
     gm.kx = (float)(1.4426950408889634 / ((double)a.sigma_x + 1e-6));
@@ -713,7 +714,7 @@ hipError_t launch_cfg(const AtrousArgs &a, hipStream_t s)
         (void)hipStreamSynchronize(s);
         unsigned long long h[16 * 16 * 8];
         (void)hipMemcpy(h, dbg_buf, sizeof(h), hipMemcpyDeviceToHost);
-        static int skip = getenv("SVGF_STRIP_DBG_SKIP") ? atoi(getenv("SVGF_STRIP_DBG_SKIP")) : 0;    // warm launches only
+        static int skip = SVGF_TUNE("strip_dbg_skip", 0);    // warm launches only
         if (skip > 0) skip--;
         else if (prints++ < 10) {
             const int nw = (TX * ROWS + kLoaderThreads) / 64;
@@ -741,7 +742,7 @@ hipError_t launch_cfg(const AtrousArgs &a, hipStream_t s)
     return hipGetLastError();
 }
 
-// default configuration per dilation; SVGF_STRIP_TX / SVGF_STRIP_ROWS override for tuning runs
+// default configuration per dilation; svgf_exp_set("strip_tx" / "strip_rows") override it in the experiments build
 void pick(int log2s, int W, int &tx, int &rows)
 {
     // 256 columns x 2 rows per workgroup everywhere (profiles/r01_exp_tx_rows.log):
@@ -751,8 +752,8 @@ void pick(int log2s, int W, int &tx, int &rows)
     //  * ROWS = 3 (12 compute waves) is correct but not faster: two compute waves already saturate a SIMD's VALU.
     (void)W;
     tx = 256; rows = 2;
-    if (const char *e = getenv("SVGF_STRIP_TX")) { int v = atoi(e); if (v == 128 || v == 256) tx = v; }
-    if (const char *e = getenv("SVGF_STRIP_ROWS")) { int v = atoi(e); if (v >= 1 && v <= 3) rows = v; }
+    if (const int v = SVGF_TUNE("strip_tx", 0); v == 128 || v == 256) tx = v;
+    if (const int v = SVGF_TUNE("strip_rows", 0); v >= 1 && v <= 3) rows = v;
     if (rows == 3 && tx != 256) rows = 2;
     // LDS budget: ring + blur rows <= 160 KiB
     const int S = 1 << log2s;
@@ -794,12 +795,16 @@ hipError_t launch_atrous_strip(const AtrousArgs &a, hipStream_t s)
     while ((1 << log2s) < a.step) log2s++;
     int tx, rows;
     pick(log2s, a.W, tx, rows);
+    // product build: 256 columns x 2 rows per workgroup at every step (what pick() returns without tuning; 155.7 KB of LDS at step 32)
+    STRIP_CASE(0, 256, 2) STRIP_CASE(1, 256, 2) STRIP_CASE(2, 256, 2) STRIP_CASE(3, 256, 2) STRIP_CASE(4, 256, 2) STRIP_CASE(5, 256, 2)
+#ifdef SVGF_BUILD_EXPERIMENTS
     STRIP_CASE(1, 256, 3) STRIP_CASE(2, 256, 3) STRIP_CASE(3, 256, 3)
-    STRIP_CASE(0, 128, 1) STRIP_CASE(0, 128, 2) STRIP_CASE(0, 256, 1) STRIP_CASE(0, 256, 2) STRIP_CASE(0, 256, 3)
-    STRIP_CASE(1, 128, 1) STRIP_CASE(1, 128, 2) STRIP_CASE(1, 256, 1) STRIP_CASE(1, 256, 2)
-    STRIP_CASE(2, 128, 1) STRIP_CASE(2, 128, 2) STRIP_CASE(2, 256, 1) STRIP_CASE(2, 256, 2)
-    STRIP_CASE(3, 128, 1) STRIP_CASE(3, 128, 2) STRIP_CASE(3, 256, 1) STRIP_CASE(3, 256, 2)
-    STRIP_CASE(4, 128, 1) STRIP_CASE(4, 128, 2) STRIP_CASE(4, 256, 1) STRIP_CASE(4, 256, 2)
-    STRIP_CASE(5, 128, 1) STRIP_CASE(5, 128, 2) STRIP_CASE(5, 256, 1) STRIP_CASE(5, 256, 2)
+    STRIP_CASE(0, 128, 1) STRIP_CASE(0, 128, 2) STRIP_CASE(0, 256, 1) STRIP_CASE(0, 256, 3)
+    STRIP_CASE(1, 128, 1) STRIP_CASE(1, 128, 2) STRIP_CASE(1, 256, 1)
+    STRIP_CASE(2, 128, 1) STRIP_CASE(2, 128, 2) STRIP_CASE(2, 256, 1)
+    STRIP_CASE(3, 128, 1) STRIP_CASE(3, 128, 2) STRIP_CASE(3, 256, 1)
+    STRIP_CASE(4, 128, 1) STRIP_CASE(4, 128, 2) STRIP_CASE(4, 256, 1)
+    STRIP_CASE(5, 128, 1) STRIP_CASE(5, 128, 2) STRIP_CASE(5, 256, 1)
+#endif
     return hipErrorInvalidValue;
 }

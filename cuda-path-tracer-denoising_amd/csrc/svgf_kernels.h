@@ -15,6 +15,16 @@
 #include <hip/hip_ext.h>
 #include <mutex>
 
+// Tuning knobs and parked kernel variants exist in the EXPERIMENTS build only (-DSVGF_BUILD_EXPERIMENTS -> libsvgf_hip_exp.so, used
+// by tools/experiments/ and the tests marked `experiments`): a name -> int table filled through svgf_exp_set().  The product build
+// compiles every SVGF_TUNE() to its default, reads no environment variable and instantiates none of the parked kernels.
+#ifdef SVGF_BUILD_EXPERIMENTS
+int svgf_exp_get(const char *name, int dflt);       // svgf_api.hip
+#define SVGF_TUNE(name, dflt) svgf_exp_get(name, dflt)
+#else
+#define SVGF_TUNE(name, dflt) (dflt)
+#endif
+
 // Profiling hand-off.  svgf_api.hip's KernelTimer arms an event pair for the NEXT kernel launch of this host thread; the launch
 // macro hands it to hipExtLaunchKernelGGL, which attaches the events to the DISPATCH itself: start / stop are the kernel's own
 // begin / end timestamps (what rocprofv3 reports), and nothing is added to the stream.  hipEventRecord pairs around a launch —
@@ -132,21 +142,25 @@ hipError_t launch_atrous_strip(const AtrousArgs &a, hipStream_t s);    // LDS st
 bool       atrous_strip_supported(const AtrousArgs &a);
 double     atrous_strip_estimate_us(const AtrousArgs &a, int n_cu);   // launch-geometry cost model (automatic kernel choice)
 hipError_t launch_atrous_lane(const AtrousArgs &a, hipStream_t s);     // lane-marching kernel, symmetric terms shared by DPP (steps 1 .. 32)
-hipError_t launch_atrous_lane_reuse(const AtrousArgs &a, hipStream_t s);   // the same with a.tin / a.tout (cross-level reuse of geometric terms)
 bool       atrous_lane_supported(const AtrousArgs &a);
 double     atrous_lane_estimate_us(const AtrousArgs &a, int n_cu);
+// non-temporal mode: the prepare pass (variance fill + G-buffer split) fused into the first level (step 2, AoS boundary;
+// svgf_atrous_prepare_fused.hip)
+hipError_t launch_atrous_prepare_fused(const AtrousArgs &a, const TemporalArgs &t, hipStream_t s);
+bool       atrous_prepare_fused_supported(const AtrousArgs &a, const TemporalArgs &t);
+#ifdef SVGF_BUILD_EXPERIMENTS
+// ---- parked variants (measured losses; experiments build only) ----
+hipError_t launch_atrous_lane_reuse(const AtrousArgs &a, hipStream_t s);   // lane kernel with a.tin / a.tout (cross-level reuse of geometric terms)
 // temporal pass fused into the first level (step 2): the lane kernel's loader waves accumulate the pixels they stage
 // (svgf_atrous_fused.hip).  t.cv_acc may be null: the accumulated colour then exists only in LDS.
 hipError_t launch_atrous_fused(const AtrousArgs &a, const TemporalArgs &t, hipStream_t s);
 bool       atrous_fused_supported(const AtrousArgs &a, const TemporalArgs &t);
 double     atrous_fused_estimate_us(const AtrousArgs &a, int n_cu);
-// non-temporal mode: the prepare pass (variance fill + G-buffer split) fused into the first level (step 2, AoS boundary)
-hipError_t launch_atrous_prepare_fused(const AtrousArgs &a, const TemporalArgs &t, hipStream_t s);
-bool       atrous_prepare_fused_supported(const AtrousArgs &a, const TemporalArgs &t);
 // temporal frames: the G-buffer split alone in the first level's loaders (the temporal pass then runs with skip_split)
 hipError_t launch_atrous_split_fused(const AtrousArgs &a, const TemporalArgs &t, hipStream_t s);
 bool       atrous_split_fused_supported(const AtrousArgs &a, const TemporalArgs &t);
 hipError_t launch_atrous_lane_2y(const AtrousArgs &a, hipStream_t s);  // step 2, both y-phases per workgroup, not fused (A/B)
+#endif
 hipError_t launch_atrous_lattice(const AtrousArgs &a, hipStream_t s);  // lattice sub-images in LDS (steps >= 64)
 bool       atrous_lattice_supported(const AtrousArgs &a);
 // albedo * ialbedo of the last level's re-modulation (:166-168), from the AoS texel or from the planar path's plane

@@ -32,7 +32,7 @@ extern "C" {
 #endif
 
 #define SVGF_VERSION_MAJOR 0
-#define SVGF_VERSION_MINOR 6
+#define SVGF_VERSION_MINOR 7
 
 /* ---- error codes (every entry point returns one of these; the library never exits) ---- */
 #define SVGF_OK                 0
@@ -82,22 +82,19 @@ typedef struct SvgfParams {
     int   kernel_variant;     /* 0 auto (steps 2-32: the cheaper of the lane-marching and the LDS strip kernel by their
                                  launch-geometry cost model — lane at 1920, 3840, 1600, 3440 columns ..., strip at 1024,
                                  2048 ...; the lane kernel at steps 16-32 also needs the variance plane the previous level
-                                 leaves; lattice sub-image kernel for steps >= 64; gather where none applies),
-                                 1 strict gather kernel,
+                                 leaves; lattice sub-image kernel for steps >= 64; gather where none applies; on NON-temporal
+                                 frames the prepare pass (variance fill + G-buffer split) rides in the first level's loader
+                                 waves whenever that level runs the lane kernel at step 2 on the AoS boundary: one launch
+                                 less, +39 % on BASELINE configs[0]),
+                                 1 strict gather kernel on every level,
                                  2 LDS strip kernel for every step 2-32 (error if a step is unsupported, raised before
-                                 anything is enqueued), 3 retired (was an experimental shared-weight kernel, now under
-                                 tools/experiments/; SVGF_ERR_INVALID_ARG), 4 lane-marching kernel wherever it is supported (steps
-                                 2-32) whatever the image width, strip / lattice for the rest; the temporal (or prepare) pass is
-                                 its own kernel,
-                                 5 as 4 with the step-2 level on the two-y-phase geometry of the fused kernel, not fused (A/B),
-                                 6 as 4 with the temporal pass fused into the first level on every frame that can be fused
-                                 (temporal and spatial on, no debug view, reference steps, no reproj_position_tol /
-                                 spatial_variance_frames), whatever the cost model says; on NON-temporal frames the prepare
-                                 pass (variance fill + G-buffer split) is fused into the first level instead.
-                                 0 fuses the temporal pass where 6 would and the cost model says it pays (at the measured speed
-                                 of that kernel: never), and the prepare pass of non-temporal frames whenever the first level
-                                 runs the lane kernel at step 2 on the AoS boundary (measured: +39 % on BASELINE configs[0])
-                                 (ABI 0.6) */
+                                 anything is enqueued),
+                                 4 lane-marching kernel wherever it is supported (steps 2-32) whatever the image width,
+                                 strip / lattice for the rest; the temporal (or prepare) pass is always its own kernel.
+                                 3 is retired (SVGF_ERR_INVALID_ARG).  5 and 6 name parked experiments (two-y-phase geometry;
+                                 temporal pass fused into the first level — measured losses) that exist only in
+                                 the experiments build of these sources (libsvgf_hip_exp.so, -DSVGF_BUILD_EXPERIMENTS): this
+                                 library answers SVGF_ERR_UNSUPPORTED, before anything is enqueued. */
     int   inputs_ready;       /* accepted and IGNORED since ABI 0.6 (everything is ordered on `stream`).  Rounds 1-3: 1 let the
                                  temporal pass of this frame run on an internal stream beside the previous frame's trailing
                                  a-trous levels; it lost 3-8 % once the lane kernel ran every level, and the fused first level
@@ -160,8 +157,21 @@ int svgf_denoise_host(svgf_ctx *ctx, float *out_rgb_host, const float *in_rgb_ho
                       const SvgfGBufferTexel *gbuffer_host, const SvgfCamera *cam,
                       const SvgfParams *params);
 
-/* Block until everything enqueued by this context has finished. */
+/* Block until everything enqueued on the context's DEVICE has finished (hipDeviceSynchronize: what the reference's denoise()
+ * ends with, src/denoise.cu:401, and what the legacy shim calls). */
 int svgf_sync(svgf_ctx *ctx);
+
+/* Stream-scoped completion (ABI 0.7): block until what has been enqueued on `stream` — the stream the frames were given to
+ * svgf_denoise with — has finished, and nothing else: a renderer with several streams does not stall the others.
+ * svgf_denoise itself never synchronises, allocates or touches another stream, so a frame may be captured into a hipGraph
+ * (hipStreamBeginCapture .. svgf_denoise .. hipStreamEndCapture) and replayed: the launches are recorded with the plane roles of
+ * the captured call, so replay a graph of TWO consecutive frames (or any even number) to keep the context's rotation consistent
+ * (tests/test_stream_gpu.py). */
+int svgf_sync_stream(svgf_ctx *ctx, void *stream);
+
+/* 0 for this (product) build; 1 for the experiments build of the same sources, which additionally accepts kernel_variant 5 / 6
+ * and exports a tuning entry point that is deliberately not declared here. */
+int svgf_build_has_experiments(void);
 
 /* Message of the last error on this context (or of the last failed svgf_create if ctx == NULL). */
 const char *svgf_last_error(const svgf_ctx *ctx);
@@ -192,7 +202,8 @@ int svgf_set_capture(svgf_ctx *ctx, int on);
 #define SVGF_KERNEL_ATROUS     3
 #define SVGF_KERNEL_DEBUGVIEW  4
 #define SVGF_KERNEL_COPYOUT    5
-#define SVGF_KERNEL_FUSED      6   /* temporal (or, on non-temporal frames, prepare) pass + first a-trous level in one launch (ABI 0.6) */
+#define SVGF_KERNEL_FUSED      6   /* prepare pass of a NON-temporal frame + first a-trous level in one launch (ABI 0.6): such a frame reports
+                                      one FUSED entry in place of PREPARE + the first ATROUS; temporal frames never do in this build */
 /* Timing source: an event pair attached to each kernel dispatch (hipExtLaunchKernelGGL): the kernel's own begin / end
  * timestamps, nothing recorded on the stream.
  * svgf_profile_stride(ctx, k): time only every k-th frame (k >= 1, default 1).

@@ -17,6 +17,8 @@ FLOAT_KEYS = {"color_alpha", "moment_alpha", "sigma_l", "sigma_x", "sigma_n"}
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "experiments: runs a parked kernel variant / tuning knob of the EXPERIMENTS build "
+                            "(libsvgf_hip_exp.so, -DSVGF_BUILD_EXPERIMENTS); the product library has none of them")
 
 
 @pytest.fixture(scope="session")
@@ -28,6 +30,26 @@ def pkg():
 @pytest.fixture(scope="session")
 def orc(pkg):
     return ge.load_oracle()
+
+
+EXPERIMENT_VARIANTS = (5, 6)     # kernel_variant values that exist in the experiments build only
+
+
+def denoiser_for(pkg, W, H, variant=0, device=0):
+    """A context in the product library, or — for the parked variants 5 / 6 — in the experiments build of the same sources."""
+    return pkg.Denoiser(W, H, device, experiments=variant in EXPERIMENT_VARIANTS)
+
+
+@pytest.fixture
+def experiments_lib(pkg, monkeypatch):
+    """Tests of parked experiments: every context / producer call of the test goes to libsvgf_hip_exp.so, with an empty tuning table
+    before and after."""
+    if not os.path.exists(pkg.binding.LIB_EXP_PATH):
+        pytest.skip("libsvgf_hip_exp.so not built (python -c 'import __graft_entry__ as g; g.build()')")
+    monkeypatch.setenv("SVGF_USE_EXPERIMENTS_LIB", "1")
+    pkg.binding.exp_clear()
+    yield pkg.binding
+    pkg.binding.exp_clear()
 
 
 def relerr(a, b):

@@ -40,7 +40,7 @@ def test_params_default_matches_reference_ui_defaults(pkg):
     q = pkg.reference_defaults()        # reference src/main.cpp:49-62
     for name, _ in pkg.SvgfParams._fields_[:15]:
         assert getattr(p, name) == pytest.approx(getattr(q, name)), name
-    assert lib.svgf_version() == (0 << 16) | 6
+    assert lib.svgf_version() == (0 << 16) | 7
 
 
 def test_params_size_is_exported_and_checked(pkg):
@@ -68,15 +68,13 @@ def test_error_paths_without_gpu(pkg):
 
 
 def test_product_never_touches_the_oracle():
-    """The shipped path must not import/link/execute anything under oracle/."""
+    """The shipped path must not import/link/execute anything under oracle/ — nor build it (oracle/build_oracle.py does)."""
     pk = os.path.join(ROOT, "cuda-path-tracer-denoising_amd")
     for dirpath, _, files in os.walk(pk):
         for f in files:
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 text = open(os.path.join(dirpath, f)).read()
-                if f == "build.py":      # builds the checker; building is not using
-                    continue
-                assert "svgf_oracle" not in text and "oracle_py" not in text, os.path.join(dirpath, f)
+                assert "svgf_oracle" not in text and "oracle_py" not in text and "build_oracle" not in text, os.path.join(dirpath, f)
     import subprocess
     out = subprocess.run(["ldd", os.path.join(pk, "libsvgf_hip.so")], stdout=subprocess.PIPE, text=True).stdout
     assert "oracle" not in out
@@ -88,3 +86,33 @@ def test_product_never_touches_the_oracle():
                 assert "load_oracle" not in text and "svgf_oracle" not in text and "oracle_py" not in text, os.path.join(dirpath, f)
     bench = open(os.path.join(ROOT, "bench.py")).read()
     assert bench.count("load_oracle") == 1 and "def cpu_baseline" in bench      # one use, inside the cpu_baseline leg
+
+
+def test_product_build_has_no_experiments_and_reads_no_environment(pkg):
+    """The product library: no getenv anywhere in csrc/ (tuning knobs are svgf_exp_set of the experiments build), no tuning entry
+    point, none of the parked kernels (FUSED = 1 / 2 / 4, two-y-phase geometry, cross-level term reuse), under 1.5 MB."""
+    import subprocess
+    pk = os.path.join(ROOT, "cuda-path-tracer-denoising_amd")
+    for f in os.listdir(os.path.join(pk, "csrc")):
+        assert "getenv" not in open(os.path.join(pk, "csrc", f)).read(), f
+    lib = os.path.join(pk, "libsvgf_hip.so")
+    syms = subprocess.run(["nm", "-D", "--defined-only", lib], stdout=subprocess.PIPE, text=True, check=True).stdout
+    exported = {ln.split()[-1] for ln in syms.splitlines() if ln.strip()}
+    assert "svgf_exp_set" not in exported and "svgf_exp_clear" not in exported
+    assert "getenv" not in subprocess.run(["nm", "-D", "--undefined-only", lib], stdout=subprocess.PIPE, text=True, check=True).stdout
+    assert os.path.getsize(lib) < 1.5 * 1024 * 1024, os.path.getsize(lib)
+    assert pkg.load_library().svgf_build_has_experiments() == 0
+    # the parked kernels: template arguments <LOG2S, HASVAR, LOG2P, LOG2Y, FUSED, REUSE> of k_atrous_lane in the device code objects
+    names = subprocess.run(["strings", "-n", "20", lib], stdout=subprocess.PIPE, text=True, check=True).stdout
+    lane = sorted({ln.strip() for ln in names.splitlines() if "k_atrous_laneILi" in ln and ln.strip().startswith("_ZN")})
+    assert lane, "the lane kernel's symbols are in the library"
+    import re
+    for sym in lane:
+        m = re.search(r"k_atrous_laneILi(\d+)ELb([01])ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)E", sym)
+        assert m, sym
+        log2y, fused, reuse = int(m.group(4)), int(m.group(5)), int(m.group(6))
+        assert log2y == 0 and fused in (0, 3) and reuse == 0, sym
+    exp = os.path.join(pk, "libsvgf_hip_exp.so")
+    if os.path.exists(exp):      # the experiments build of the same sources carries what the product build leaves out
+        e = pkg.load_library(experiments=True)
+        assert e.svgf_build_has_experiments() == 1 and hasattr(e, "svgf_exp_set")

@@ -15,7 +15,13 @@ import pytest
 
 from conftest import relerr
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.experiments]
+
+
+@pytest.fixture(autouse=True)
+def _experiments_build(experiments_lib):
+    """kernel_variant 6 (the parked fused temporal + first-level kernel) exists in libsvgf_hip_exp.so only."""
+    yield
 
 SIZES = [(320, 180), (257, 131), (1920, 38), (500, 37), (33, 7), (241, 64), (239, 5), (1, 1), (5, 3), (960, 90)]
 

@@ -5,7 +5,7 @@ against the CPU oracle on every frame.  60 sequences x 3 frames; the bar is the 
 import numpy as np
 import pytest
 
-from conftest import relerr
+from conftest import denoiser_for, relerr
 
 pytestmark = pytest.mark.gpu
 
@@ -32,7 +32,7 @@ def test_random_sequences_match_the_oracle(pkg, orc, block):
     for case in range(10):
         W, H, kw = _draw(rng)
         moving = bool(rng.integers(0, 2))
-        d = pkg.Denoiser(W, H, 0)
+        d = denoiser_for(pkg, W, H, kw["kernel_variant"])      # (variant 6: the experiments build, see conftest)
         o = orc.Oracle(pkg, W, H, threads=4)
         big_steps = False
         for f in range(3):

@@ -10,7 +10,7 @@ relerr() uses max(|ref|, 1e-2) as the denominator.
 import numpy as np
 import pytest
 
-from conftest import golden_cases, load_golden, relerr, replay
+from conftest import denoiser_for, golden_cases, load_golden, relerr, replay
 
 pytestmark = pytest.mark.gpu
 
@@ -22,7 +22,7 @@ class Engine:
     """Adapter: Denoiser with the replay() interface (numpy in / numpy out through svgf_denoise_host)."""
 
     def __init__(self, pkg, W, H, variant=0):
-        self.d = pkg.Denoiser(W, H, device=0)
+        self.d = denoiser_for(pkg, W, H, variant)       # (variants 5 / 6: the experiments build of the same sources)
         self.variant = variant
 
     def reset(self):
@@ -44,12 +44,13 @@ def native_loaded(pkg):
     assert lib.svgf_version() > 0
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 4, 5, 6])
+@pytest.mark.parametrize("variant", [0, 1, 2, 4, pytest.param(5, marks=pytest.mark.experiments), pytest.param(6, marks=pytest.mark.experiments)])
 @pytest.mark.parametrize("name", CASES)
 def test_hip_matches_reference_goldens(pkg, name, variant):
-    """variant 0: the library's choice (fused temporal + first level where its cost model says so), 1 gather, 2 strip,
-    4 lane kernels with the temporal pass on its own, 5 the fused kernel's two-y-phase geometry without the fusion,
-    6 fused on every frame that can be."""
+    """variant 0: the library's choice (prepare pass of non-temporal frames in the first level's loaders), 1 gather, 2 strip,
+    4 lane kernels with the temporal / prepare pass on its own; in the experiments build (libsvgf_hip_exp.so) also 5, the fused
+    kernel's two-y-phase geometry without the fusion, and 6, the temporal pass fused into the first level on every frame that
+    can be."""
     z, runs = load_golden(name)
     W, H = int(z["W"]), int(z["H"])
     for tag in runs:
@@ -385,6 +386,9 @@ def test_error_codes(pkg):
         d.denoise_host(c, g, cam, pkg.reference_defaults().set(spatial_enable=1, atrous_nlevel=6, kernel_variant=2))
     with pytest.raises(pkg.SvgfError, match="no longer part of the library"):
         d.denoise_host(c, g, cam, pkg.reference_defaults().set(spatial_enable=1, kernel_variant=3))
+    for v in (5, 6):       # parked experiments: not in the product build, refused before anything is enqueued
+        with pytest.raises(pkg.SvgfError, match="-5.*parked experiment"):
+            d.denoise_host(c, g, cam, pkg.reference_defaults().set(spatial_enable=1, kernel_variant=v))
     with pytest.raises(pkg.SvgfError, match="null argument"):
         d.denoise(None, None, None, cam, pkg.reference_defaults())
     out = d.denoise_host(c, g, cam, pkg.reference_defaults())      # the context stays usable after errors
@@ -393,16 +397,16 @@ def test_error_codes(pkg):
     lib = pkg.load_library()
     h = ctypes.c_void_p()
     assert lib.svgf_create(99, 8, 8, ctypes.byref(h)) == -2
+    assert lib.svgf_build_has_experiments() == 0 and not hasattr(lib, "svgf_exp_set")
 
 
-@pytest.mark.gpu
-@pytest.mark.parametrize("env", [{"SVGF_STRIP_ROWS": "3"}, {"SVGF_STRIP_TX": "128"}, {"SVGF_STRIP_ROWS": "1"},
-                                 {"SVGF_STRIP_TX": "128", "SVGF_STRIP_ROWS": "1"}])
-def test_strip_kernel_tuning_configurations_stay_correct(pkg, env, monkeypatch):
-    """The strip kernel's alternative shapes (12 compute waves, 128-column strips, one row per iteration) are only
-    reachable through tuning environment variables; they must keep giving the reference's result."""
-    for k, v in env.items():
-        monkeypatch.setenv(k, v)
+@pytest.mark.experiments
+@pytest.mark.parametrize("knobs", [{"strip_rows": 3}, {"strip_tx": 128}, {"strip_rows": 1}, {"strip_tx": 128, "strip_rows": 1}])
+def test_strip_kernel_tuning_configurations_stay_correct(pkg, knobs, experiments_lib):
+    """The strip kernel's alternative shapes (12 compute waves, 128-column strips, one row per iteration) exist in the experiments
+    build only, behind svgf_exp_set; they must keep giving the reference's result."""
+    for k, v in knobs.items():
+        experiments_lib.exp_set(k, v)
     for name in ("atrous_rand37x23_n5", "atrous_synth128x72_n5", "atrous_nanpos40x32_n2", "full_static96x54"):
         if name not in CASES:
             continue
@@ -415,7 +419,7 @@ def test_strip_kernel_tuning_configurations_stay_correct(pkg, env, monkeypatch):
             got = replay(pkg, e, z, tag)
             e.free()
             err = relerr(got, z[f"ref_nofma_out_{tag}"])
-            assert err.max() <= TOL_STRIP, f"{env} {name}:{tag} max rel {err.max():.3e}"
+            assert err.max() <= TOL_STRIP, f"{knobs} {name}:{tag} max rel {err.max():.3e}"
 
 
 def test_1080p_moving_64_frames_full_svgf_every_frame(pkg, orc):

@@ -7,7 +7,7 @@ import ctypes
 import numpy as np
 import pytest
 
-from conftest import golden_cases, load_golden, replay
+from conftest import denoiser_for, golden_cases, load_golden, replay
 
 pytestmark = pytest.mark.gpu
 
@@ -185,7 +185,7 @@ def test_planar_pointers_survive_a_reset_and_the_fused_first_level_reads_planes(
         for reset_at in (1, 2):
             res = {}
             for planar in (False, True):
-                d = pkg.Denoiser(W, H, 0)
+                d = denoiser_for(pkg, W, H, variant)      # (variant 6: the experiments build)
                 outs = []
                 for f in range(5):
                     cam = pkg.synth.camera_for_frame(f, True)

@@ -9,7 +9,7 @@ plane is written when — and only when — something besides the first level re
 import numpy as np
 import pytest
 
-from conftest import relerr
+from conftest import denoiser_for, relerr
 
 pytestmark = pytest.mark.gpu
 
@@ -21,8 +21,10 @@ def _seq(pkg, W, H, n, moving=True, seed=17):
 
 
 def _run(pkg, W, H, frames, modes, variant, capture=False, **kw):
-    """modes[f] = temporal_enable of frame f."""
-    d = pkg.Denoiser(W, H, 0)
+    """modes[f] = temporal_enable of frame f.  (kernel_variant 6 — force the fusion whatever the cost model says — exists in the
+    experiments build only: the same FUSED = 3 instantiation of the same sources; the product library's own copy runs wherever
+    variant 0 chooses the lane kernel for the first level: 800x800, 1920x38, 961x90, 481x64 ... below.)"""
+    d = denoiser_for(pkg, W, H, variant)
     d.set_capture(capture)
     res = []
     for (c, g, cam), t in zip(frames, modes):
@@ -83,7 +85,7 @@ def test_fused_prepare_against_the_oracle_and_the_colour_plane_when_it_is_needed
 def test_fused_prepare_with_non_finite_texels_and_misses(pkg, orc):
     W, H = 300, 97
     rng = np.random.default_rng(5)
-    d = pkg.Denoiser(W, H, 0)
+    d = denoiser_for(pkg, W, H, 6)
     o = orc.Oracle(pkg, W, H, threads=8)
     for f in range(3):
         c, g, cam = pkg.synth.render_frame(W, H, f, seed=7, moving=True)

@@ -1,5 +1,5 @@
 """Cross-level reuse of the geometric terms (svgf_atrous_lane_reuse.hip; off by default because it measured slower, on with
-the environment variable SVGF_REUSE=1 at svgf_create): a lane-kernel level stores four of its pair terms per pixel and the
+svgf_exp_set("reuse", 1) before svgf_create, experiments build only): a lane-kernel level stores four of its pair terms per pixel and the
 next level reads them instead of evaluating them.  Same results as without it to rounding (g + c instead of fma(dx, kx,
 fma(dn, kn, c))), checked against the CPU oracle at sizes that take the lane kernel on every level, with non-finite texels (the
 careful path has to hand on usable terms too) and with the paper's dilation sequence."""
@@ -8,14 +8,14 @@ import pytest
 
 from conftest import relerr
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.experiments]
 
 
 @pytest.mark.parametrize("size,kw", [((1920, 70), dict()), ((300, 200), dict(kernel_variant=4)), ((123, 77), dict(kernel_variant=4, blur_variance=0)),
                                      ((641, 97), dict(kernel_variant=4, paper_steps=1, atrous_nlevel=6)), ((480, 33), dict(kernel_variant=4, atrous_nlevel=3, history_level=2))],
                          ids=["1920x70-auto", "300x200", "123x77-noblur", "641x97-paper-steps", "480x33-three-levels"])
-def test_reuse_of_geometric_terms_matches_oracle(pkg, orc, size, kw, monkeypatch):
-    monkeypatch.setenv("SVGF_REUSE", "1")
+def test_reuse_of_geometric_terms_matches_oracle(pkg, orc, size, kw, experiments_lib):
+    experiments_lib.exp_set("reuse", 1)
     W, H = size
     p = pkg.reference_defaults().set(temporal_enable=1, spatial_enable=1, **kw)
     d = pkg.Denoiser(W, H, 0)

@@ -1,0 +1,10 @@
+# round 5: build libsvgf_hip.so.<tag> for a list of "tag=flags" pairs (flags separated by ';'), here in the container
+# usage: exp_r05_build_variants.sh "A=-DSVGF_LANE_SKEW=0" "B=-DSVGF_LANE_SKEW=1;-DSVGF_LANE_PRIO=1,1,2,1,1,2,2"
+L=cuda-path-tracer-denoising_amd/libsvgf_hip.so
+for spec in "$@"; do
+  tag=${spec%%=*}; flags=${spec#*=}; flags=${flags//;/ }
+  SVGF_EXTRA_HIPCC_FLAGS="$flags" python -c "
+import __graft_entry__ as g
+pkg=g.load_package(); pkg.build.build_hip(force=True)" || exit 1
+  cp $L $L.$tag; echo "built $tag: $flags"
+done

@@ -48,7 +48,7 @@ def main():
     out = torch.empty((H, W, 3), dtype=torch.float32, device="cuda")
     results = {}
     for v in [int(x) for x in a.variants.split(",")]:
-        d = pkg.Denoiser(W, H, 0)
+        d = pkg.Denoiser(W, H, 0, experiments=v in (5, 6))      # parked variants live in libsvgf_hip_exp.so (SVGF_USE_EXPERIMENTS_LIB=1: everything does)
         p = pkg.reference_defaults().set(temporal_enable=1, spatial_enable=1, atrous_nlevel=a.nlevel, kernel_variant=v, inputs_ready=a.overlap, blur_variance=a.blur)
         if a.planar:      # both plane sets (they alternate with the history) get the static scene's G-buffer; d.denoise then means denoise_planar
             cam_dict = pkg.synth.camera_for_frame(0, False)

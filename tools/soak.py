@@ -30,8 +30,8 @@ def main():
     import torch
     pkg = ge.load_package()
     W, H = map(int, a.size.split("x"))
-    da, db = pkg.Denoiser(W, H), pkg.Denoiser(W, H)
     vb = {"default-fused": 6, "default-gather": 1, "same": 0}[a.pair]
+    da, db = pkg.Denoiser(W, H), pkg.Denoiser(W, H, experiments=(vb == 6))      # (the parked fused kernel lives in libsvgf_hip_exp.so)
     pa = pkg.reference_defaults().set(temporal_enable=1, spatial_enable=1, atrous_nlevel=5, history_level=1, inputs_ready=1)
     pb = pkg.reference_defaults().set(temporal_enable=1, spatial_enable=1, atrous_nlevel=5, history_level=1, inputs_ready=0, kernel_variant=vb)
     nbuf = 64    # a 64-frame moving-camera sequence produced up front and replayed, so calls go back to back
