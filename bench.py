@@ -45,7 +45,7 @@ def kernel_sources_sha16():
     """Fingerprint of the a-trous kernel sources the PMC traffic record belongs to."""
     import hashlib
     h = hashlib.sha256()
-    for name in ("svgf_atrous_lane_impl.h", "svgf_atrous_lane.hip", "svgf_atrous_fused.hip", "svgf_atrous_strip.hip", "svgf_api.hip"):
+    for name in ("svgf_atrous_lane_impl.h", "svgf_atrous_lane.hip", "svgf_atrous_prepare_fused.hip", "svgf_atrous_strip.hip", "svgf_api.hip"):
         with open(os.path.join(ROOT, "cuda-path-tracer-denoising_amd", "csrc", name), "rb") as f:
             h.update(f.read())
     return h.hexdigest()[:16]
@@ -93,7 +93,7 @@ def cgroup_cpu_quota():
     return None
 
 
-def cpu_baseline(pkg, frames, params, budget_s=25.0, threads=None, what="full-SVGF", all_cores=True):
+def cpu_baseline(pkg, frames, params, budget_s=25.0, threads=None, what="full-SVGF", all_cores=True, min_frames=5, one_thread=True):
     """CPU oracle (oracle/svgf_oracle.c, OpenMP) on the same workload, bounded sample.  Threads are bound one per physical
     core (OMP_PLACES=cores, OMP_PROC_BIND=spread, set in main() before libgomp starts) and rows are dealt in static blocks, so
     that the all-cores figure is not the SMT + unbound one of round 2 (slower than 64 threads)."""
@@ -107,25 +107,39 @@ def cpu_baseline(pkg, frames, params, budget_s=25.0, threads=None, what="full-SV
     usable = min(cores, quota) if quota else cores
     threads = min(usable, 64) if threads is None else threads
     o = orc.Oracle(pkg, W, H, threads=threads)
-    t_all, n = 0.0, 0
+    ts = []
     t_start = time.perf_counter()
-    for f in range(4):
+    for f in range(1 + max(5, min_frames)):
         c, g, cam = frames[f % len(frames)]
         t0 = time.perf_counter()
         o.denoise(c, g, cam, params)
         dt = time.perf_counter() - t0
         if f >= 1:                       # frame 0 has no history (cheaper temporal pass): not representative
-            t_all += dt; n += 1
-        if time.perf_counter() - t_start > budget_s and n >= 1:
+            ts.append(dt)
+        if time.perf_counter() - t_start > budget_s and len(ts) >= 1:
             break
     o.free()
-    res = {"value": round(W * H / (t_all / n) / 1e6, 3), "unit": "Mpixels/s", "cores": threads, "kind": "port",
+    n = len(ts)
+    mp = lambda t: round(W * H / t / 1e6, 3)      # noqa: E731
+    res = {"value": mp(float(np.median(ts))), "unit": "Mpixels/s", "cores": threads, "kind": "port",
+           "statistic": "median over the sampled frames", "frames": n, "min": mp(max(ts)), "max": mp(min(ts)),
            "kind_note": "oracle/svgf_oracle.c, the CPU restatement of src/denoise.cu pinned to the reference's own outputs (SURVEY.md 8(d) "
                         "allows it as the CPU baseline); NOT the reference's source rebuilt for CPU, which north_star words",
            "sample": f"{n} steady-state frames of the same {W}x{H} {what} workload, oracle/svgf_oracle.c "
                      f"(gcc -O2, OpenMP static row blocks, threads bound to cores; {threads} threads; host: {cores} physical cores, "
                      f"{os.cpu_count()} hardware threads, {cpu_model}; container CPU quota: {quota if quota else 'none'})",
            "host": {"physical_cores": cores, "hardware_threads": os.cpu_count(), "cpu_model": cpu_model, "cgroup_cpu_quota": quota}}
+    if one_thread and threads > 1:           # the scalar figure beside it (BASELINE configs[0] words its CPU leg "single-threaded")
+        o1 = orc.Oracle(pkg, W, H, threads=1)
+        t1 = []
+        for f in range(3):
+            c, g, cam = frames[f % len(frames)]
+            t0 = time.perf_counter()
+            o1.denoise(c, g, cam, params)
+            if f >= 1:
+                t1.append(time.perf_counter() - t0)
+        o1.free()
+        res["one_thread"] = {"value": mp(float(np.median(t1))), "unit": "Mpixels/s", "cores": 1, "frames": len(t1), "min": mp(max(t1)), "max": mp(min(t1))}
     if all_cores and usable > threads:       # north_star: "the same box's host cores" — every core the container may use
         oa = orc.Oracle(pkg, W, H, threads=usable)
         ts = []
@@ -141,16 +155,33 @@ def cpu_baseline(pkg, frames, params, budget_s=25.0, threads=None, what="full-SV
     return res
 
 
+def pkg_cpu_slice(rank, world):
+    """N > 1: each rank's host thread (and its telemetry sampler) is pinned to its own slice of the CPUs this process may use, so
+    that eight launch loops on a 16-CPU cgroup do not migrate over each other.  Returns the slice (None: not pinned)."""
+    if world <= 1:
+        return None
+    try:
+        cpus = sorted(os.sched_getaffinity(0))
+        per = max(1, len(cpus) // world)
+        mine = cpus[(rank * per) % len(cpus):(rank * per) % len(cpus) + per] or cpus
+        os.sched_setaffinity(0, mine)
+        return mine
+    except (AttributeError, OSError):
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--config", default="1080p-static", choices=["1080p-static", "1080p-moving", "4k-static", "4k-moving", "config1"],
+    ap.add_argument("--config", default="1080p-static", choices=["1080p-static", "1080p-moving", "4k-static", "4k-moving", "4k-room", "config1"],
                     help="1080p-static = BASELINE configs[1] (the default, the headline metric); 1080p-moving = configs[2] "
-                         "(64-frame moving-camera sequence); 4k-static = configs[3]; 4k-moving = the same at 3840x2160; config1 = "
-                         "configs[0]: 800x800, temporal off, one a-trous level, CPU leg single-threaded")
+                         "(64-frame moving-camera sequence); 4k-static = configs[3]; 4k-moving = the same at 3840x2160; 4k-room = "
+                         "configs[4] as worded: room.txt (its primitives + 2 810 triangles, ray-cast by the device producer) at "
+                         "3840x2160, one independent frame sequence per GPU — the command for the 8-GPU node is `bench.py --gpus 8 "
+                         "--config 4k-room`; config1 = configs[0]: 800x800, temporal off, one a-trous level, CPU leg single-threaded")
     ap.add_argument("--kernel-variant", type=int, default=0,
                     help="SvgfParams::kernel_variant (0 = the library's default choice; 2 strip, 4 lane-marching kernel ...)")
     ap.add_argument("--overlap", action="store_true",
@@ -217,6 +248,7 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    cpus_of_rank = pkg_cpu_slice(rank, world)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
@@ -240,7 +272,23 @@ def main():
     # every rank owns one independent sequence (its own seed); 4 distinct noisy frames, static camera, resident in HBM
     seq = pkg.farm.shard(world, world, rank)[0]
     nsrc = 64 if moving else 4
-    if a.host_inputs:
+    if a.config == "4k-room":
+        # BASELINE configs[4]: room.txt at 3840x2160.  The scene's primitives and triangles are data made from the reference's files
+        # by tests/golden/make_producer_inputs.py (the reference itself does not exist on the GPU box); the device producer
+        # ray-casts them (svgf_scene_render_mesh) with the reference's camera, static, noise stream seeded per rank.
+        gd = os.path.join(ROOT, "tests", "golden", "ref_scenes")
+        pi = np.load(os.path.join(gd, "room_producer_inputs.npz"))
+        rec = json.load(open(os.path.join(gd, "scene_records.json")))["room"]["camera"]
+        sc = pkg.scene.Scene(materials={}, objects=[], camera=dict(eye=rec["position"], lookat=rec["lookAt"], fovy=rec["fov"][1]), skipped=[])
+        cam_dicts = [pkg.scene.camera_for_frame(sc, 0, False) for f in range(nsrc)]
+        d_in = [torch.empty((H, W, 3), dtype=torch.float32, device=dev) for _ in range(nsrc)]
+        d_g = [torch.empty((H * W * 52,), dtype=torch.uint8, device=dev) for _ in range(nsrc)]
+        for f in range(nsrc):
+            pkg.binding.scene_render_mesh(d_in[f], d_g[f], W, H, cam_dicts[f], pi["geoms"], pi["geom_ids"], pi["tris"], pi["tri_ids"], pi["tri_albedo"],
+                                          frame=f, seed=1000 + seq, device=local_rank)
+        torch.cuda.synchronize(dev)
+        frames = None
+    elif a.host_inputs:
         frames = [pkg.synth.render_frame(W, H, f, seed=1000 + seq, moving=moving, noise_model="hash") for f in range(nsrc)]
         d_in = [torch.from_numpy(f[0]).to(dev) for f in frames]
         d_g = [torch.from_numpy(f[1].view(np.uint8).reshape(-1)).to(dev) for f in frames]
@@ -286,8 +334,15 @@ def main():
     if not os.environ.get("SVGF_BENCH_NO_TELEMETRY"):
         tm_all.start()
     # warm-up is run with profiling slots too, then the frame counter restarts so slots hold the timed steps only
+    # the first 12 frames of the process (cold: clocks and socket power not ramped yet): timed, part of the warm-up
+    torch.cuda.synchronize(dev)
+    t_c0 = time.perf_counter()
+    for i in range(12):
+        step(i)
+    torch.cuda.synchronize(dev)
+    cold_ms = (time.perf_counter() - t_c0) / 12 * 1e3
     t_w = time.perf_counter()
-    n_w = 0
+    n_w = 12
     while n_w < a.warmup or time.perf_counter() - t_w < a.min_warmup_seconds:
         step(n_w)
         n_w += 1
@@ -299,6 +354,13 @@ def main():
     t_region0 = time.perf_counter()
     dt, pixels = pkg.farm.timed_region(step, a.steps, 0, lambda: torch.cuda.synchronize(dev), dist=dist, device=None if share_device else dev)
     t_region1 = time.perf_counter()
+    # every rank's own clock around its own K steps (the reduction above keeps only the maximum), its device and its CPU slice
+    mine = {"rank": rank, "device": local_rank, "device_name": torch.cuda.get_device_name(dev), "ms_per_step": round(pkg.farm.last_local_seconds() / a.steps * 1e3, 5),
+            "cpus": cpus_of_rank}
+    per_rank = [mine]
+    if dist is not None and world > 1:
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
 
     # per-kernel durations of the timed steps (HIP events attached to the dispatches on the launch stream)
     atrous_ms, temporal_ms, fused_ms = [], [], []
@@ -356,22 +418,34 @@ def main():
         iso_atrous_ms = [ms for s in range(den.profile_frames()) for kind, ms in den.profile_read(s) if kind == pkg.binding.KERNEL_FUSED]
 
     if rank == 0:
-        traffic, traffic_note = None, "no PMC record"
-        try:   # HBM bytes per launch from the committed PMC passes (profiles/pmc_traffic.json).  Counter passes cannot run
-            # inside the timed region, so the figure is only reported while the kernels it was measured on are unchanged.
+        traffic, traffic_note, sq_rec = None, "no PMC record", None
+        try:   # HBM bytes per launch and SIMD activity from the committed PMC passes (profiles/pmc_traffic.json).  Counter passes
+            # cannot run inside the timed region, so the figures are only reported while the kernels they were measured on are unchanged.
             with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
                 rec = json.load(f)
             if rec.get("kernel_sources_sha16") == kernel_sources_sha16():
-                traffic, traffic_note = rec["mean_bytes_per_launch"], "measured on these kernel sources (sha16 " + rec["kernel_sources_sha16"] + ")"
+                r_hbm = rec.get("by_resolution", {}).get(f"{W}x{H}")
+                if r_hbm and a.config in ("1080p-static", "4k-static") and a.kernel_variant == 0 and not a.planar_inputs:
+                    traffic = r_hbm["mean_bytes_per_launch"]
+                    traffic_note = f"measured on these kernel sources (sha16 {rec['kernel_sources_sha16']}) at {W}x{H}, {r_hbm.get('source_file', '')}"
+                else:
+                    traffic_note = f"no PMC pass for this workload ({a.config}, {W}x{H})"
+                sq_rec = rec.get("sq_activity", {}).get(f"{W}x{H}")
             else:
                 traffic_note = "dropped: the a-trous kernel sources changed since the PMC passes (profiles/pmc_traffic.json)"
         except Exception:
             traffic = None
         value = pixels / dt / 1e6
         a_ms = float(np.mean(atrous_ms))
-        achieved = ATROUS_BYTES_PER_PIXEL * W * H / (a_ms * 1e-3) / 1e9
+        # algorithmic bytes of the timed launch: 56 B/px for a plain level; the fused prepare + level launch of config1 reads the
+        # 1-spp colour (12) and the G-buffer fields it needs (normal, position, geomId: 28) and writes the output (12) and the split
+        # planes (28) — and, when something besides this level reads them, the colour + variance plane (16) and the level's own (16)
+        bytes_px = ATROUS_BYTES_PER_PIXEL
+        if level_is_fused:
+            bytes_px = 12.0 + 28.0 + 12.0 + 28.0 + (16.0 if params.history_level != 1 else 0.0) + (16.0 if params.atrous_nlevel > 1 or params.history_level == 1 else 0.0)
+        achieved = bytes_px * W * H / (a_ms * 1e-3) / 1e9
         iso_us = float(np.mean(iso_atrous_ms)) * 1e3
-        iso_gbs = ATROUS_BYTES_PER_PIXEL * W * H / (iso_us * 1e-6) / 1e9
+        iso_gbs = bytes_px * W * H / (iso_us * 1e-6) / 1e9
         line = {
             "metric": ("SVGF Mpixels/s (one non-temporal level, BASELINE configs[0]) at 800x800; \u00e0-trous HBM GB/s vs roofline" if a.config == "config1"
                        else "SVGF Mpixels/s (full pipeline) at 4K; \u00e0-trous HBM GB/s vs roofline" if a.config.startswith("4k")
@@ -379,6 +453,10 @@ def main():
             "value": round(value, 2), "unit": "Mpixels/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "warmup_steps_run": n_w,
             "ms_per_step": round(dt / a.steps * 1e3, 5), "higher_is_better": True, "scaling": "weak",
+            # which state of the GPU the K timed steps ran in: "sustained" = directly behind >= min_warmup_seconds of
+            # back-to-back frames; `cold_ms_per_step` = the first 12 frames of this process (rank 0), for comparison
+            "state": "sustained", "sustained_after_s": round(t_warm_end - t_c0, 3), "cold_ms_per_step": round(cold_ms, 5),
+            "per_rank": per_rank,
             # one svgf_denoise + svgf_sync, median of the calls below (host wall clock around the pair)
             "latency_ms_sync": round(float(np.median(lat_ms)), 5),
             "latency": {"calls": len(lat), "warmup_calls": 10, "median_ms": round(float(np.median(lat_ms)), 5),
@@ -390,6 +468,7 @@ def main():
                           "isolated_16_frames": tm_all.summary(t_iso0, t_iso1)},
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": (f"cornell-like {W}x{H}, variance fill + ONE a-trous level (temporal off), " if a.config == "config1" else
+                                    f"room.txt (primitives + 2 810 triangles, device ray-cast) {W}x{H}, full SVGF (temporal + 5 a-trous levels, history_level 1), " if a.config == "4k-room" else
                                     f"cornell-like {W}x{H}, full SVGF (temporal + 5 a-trous levels, history_level 1), ")
                                    + ("moving camera, 64-frame sequence replayed" if moving else "static camera, steady-state history")
                                    + ("; G-buffer handed over as planes written in place by the producer (svgf_denoise_planar)" if a.planar_inputs else "")
@@ -400,7 +479,7 @@ def main():
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "traffic_measured_live": False, "traffic_provenance": traffic_note,
                          "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, profiles/pmc_traffic.json (FETCH x2 per MI355X_MICROARCH.md)",
-                         "kernel": "one plain a-trous level: k_atrous_lane (steps 4-32 when the first level is fused with the temporal pass, else 2-32; k_atrous_strip where the library's cost model prefers it); mean over those launches of a frame; the fused temporal + first-level launch is reported under kernels_us", "bytes_per_launch": ATROUS_BYTES_PER_PIXEL * W * H,
+                         "kernel": "one a-trous level: k_atrous_lane (steps 2-32; k_atrous_strip where the library's cost model prefers it), mean over the level launches of the timed frames; in config1 the one launch per frame that carries the prepare pass in its loader waves", "bytes_per_launch": bytes_px * W * H, "bytes_per_pixel": bytes_px,
                          "mean_launch_us": round(a_ms * 1e3, 2), "launches_timed": len(atrous_ms),
                          "launch_includes_fused_prepare_pass": level_is_fused,
                          "note": "everything ordered on one stream; durations are the dispatches' own begin / end timestamps (HIP events attached by hipExtLaunchKernelGGL on the launch stream, every 10th timed frame); 'isolated' repeats the measurement on every kernel of 16 frames",
@@ -408,19 +487,23 @@ def main():
                                       "frac": round(iso_gbs / HBM_PEAK_GBS, 4), "launches_timed": len(iso_atrous_ms)},
                          # the secondary limiter.  24 taps x (2 v_sqrt + 1 v_exp) + 5 (centre, normalisation) per pixel-level
                          "transcendental_gops_isolated": round(77 * W * H / (iso_us * 1e-6) / 1e9, 1),
+                         "transcendental_gops_isolated_is": "a formula, not a counter: 77 transcendental operations per pixel-level x pixels / the isolated launch duration",
                          # what actually bounds the kernel: SIMD instruction issue, 3/4 of it fp32 VALU.
                          # ~950 flop per pixel-level (24 taps x 37 + centre/normalisation) against the 157.3 TFLOP/s
                          # packed-fp32 vector peak; the PMC figure (SQ_ACTIVE_INST_ANY / SIMD time) is in profiles/.
                          "valu_view": {"fp32_tflops_isolated": round(950 * W * H / (iso_us * 1e-6) / 1e12, 1),
-                                       "fp32_vector_peak_tflops": 157.3, "simd_instruction_active_pmc": 1.0}},
+                                       "fp32_tflops_isolated_is": "a formula, not a counter: 950 flop per pixel-level x pixels / the isolated launch duration",
+                                       "fp32_vector_peak_tflops": 157.3,
+                                       # SQ_ACTIVE_INST_ANY x 4 / (launch duration x sclk x 1024 SIMDs) of the committed SQ pass, or null
+                                       "simd_instruction_active_pmc": sq_rec["simd_instruction_active_mean"] if sq_rec else None,
+                                       "simd_instruction_active_pmc_source": (f"profiles/pmc_traffic.json sq_activity[{W}x{H}] ({', '.join(sq_rec['source_files'])}; sclk {sq_rec['sclk_mhz']:.0f} MHz)"
+                                                                              if sq_rec else "no SQ pass recorded for these kernel sources at this size")}},
             "kernels_us": {"temporal": round(float(np.mean(temporal_ms)) * 1e3, 2) if temporal_ms else None,
-                           "fused_temporal_plus_level1": round(float(np.mean(fused_ms)) * 1e3, 2) if fused_ms else None,
+                           "fused_prepare_plus_level1": round(float(np.mean(fused_ms)) * 1e3, 2) if fused_ms else None,
                            "atrous_level_mean": round(a_ms * 1e3, 2), "atrous_launches_per_frame": round(len(atrous_ms) / max(1, len(fused_ms) + len(temporal_ms)), 2) if (fused_ms or temporal_ms) else None},
             "frame_algorithmic_gbs": round((ATROUS_BYTES_PER_PIXEL if a.config == "config1" else FRAME_BYTES_PER_PIXEL)
                                            * W * H / (dt / a.steps) / 1e9 / world * 1.0, 1),
         }
-        if a.config != "1080p-static":
-            line["roofline"]["traffic"] = None      # the committed PMC passes are for the 1080p-static workload
         if world == 1 and not a.no_cpu_baseline and a.config in ("1080p-static", "config1"):
             if frames is None:   # bring the device-produced frames to the host for the CPU leg
                 frames = [(d_in[f].cpu().numpy(), d_g[f].cpu().numpy().view(pkg.synth.GBUFFER_DTYPE).reshape(H, W), cam_dicts[f])

@@ -15,6 +15,14 @@ def shard(n_items: int, world_size: int, rank: int) -> list[int]:
     return list(range(rank, n_items, world_size))
 
 
+_last_local = 0.0
+
+
+def last_local_seconds() -> float:
+    """This rank's own elapsed time of the last timed_region() (before the MAX over ranks)."""
+    return _last_local
+
+
 def timed_region(step_fn, steps: int, warmup: int, sync_fn, dist=None, device=None):
     """Run `warmup` untimed steps, then time exactly `steps` steps bracketed by barrier + device sync on both sides.
     Returns (max-over-ranks seconds, sum-over-ranks of the per-step work units returned by step_fn)."""
@@ -30,6 +38,8 @@ def timed_region(step_fn, steps: int, warmup: int, sync_fn, dist=None, device=No
     for i in range(steps):
         units += float(step_fn(warmup + i))
     sync_fn()
+    global _last_local
+    _last_local = time.perf_counter() - t0       # this rank's own steps, before it waits for the others
     if dist is not None:
         dist.barrier()
     sync_fn()

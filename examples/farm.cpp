@@ -1,0 +1,95 @@
+// examples/farm.cpp — N independent frame sequences on N GPUs from ONE C++ process, through the C ABI (include/svgf.h).
+//
+// What a renderer-side farm looks like (north_star: "independent frames/tiles are farmed across the 8 GPUs of one node as an
+// embarrassingly-parallel batch (no RCCL collectives)", host code C++): one host thread, one svgf_ctx and one stream per GPU; the
+// lifecycle per context is the reference's (src/main.cpp:192-201: denoiseFree + denoiseInit on reset, denoise per frame,
+// denoiseFree at exit), handle-based instead of global.  Inputs come from the library's device-side producer (svgf_synth_render:
+// the path tracer's role), so nothing crosses PCIe in the loop.  With fewer GPUs than contexts the contexts share devices
+// (context k on device k mod n_devices) — which is how tests/test_dropin_gpu.py runs it on a one-GPU box.
+//
+//   hipcc --offload-arch=gfx950 -O2 -I include examples/farm.cpp -L cuda-path-tracer-denoising_amd -lsvgf_hip \
+//         -Wl,-rpath,$PWD/cuda-path-tracer-denoising_amd -o examples/farm
+//   examples/farm [contexts=8] [frames=64] [width=3840] [height=2160]
+//
+// Prints one line per context (device, frames, ms per frame, a checksum of the last output) and the aggregate Mpixels/s =
+// pixels of all contexts / the slowest context's time — the same reduction bench.py does across processes.
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <thread>
+#include <vector>
+
+#include "svgf.h"
+
+struct Result { int device = -1; int rc = 0; double seconds = 0.0; double checksum = 0.0; char err[256] = ""; };
+
+static void run_context(int k, int device, int W, int H, int frames, Result *r)
+{
+    r->device = device;
+    const size_t n = (size_t)W * H;
+    svgf_ctx *ctx = nullptr;
+    float *rgb = nullptr, *out = nullptr;
+    void *gbuf = nullptr;
+    hipStream_t s = nullptr;
+    auto fail = [&](const char *what, int rc) {
+        r->rc = rc ? rc : -1;
+        snprintf(r->err, sizeof(r->err), "%s: %s", what, ctx ? svgf_last_error(ctx) : svgf_last_error(nullptr));
+    };
+    do {
+        if (hipSetDevice(device) != hipSuccess) { fail("hipSetDevice", SVGF_ERR_NO_DEVICE); break; }
+        if (int rc = svgf_create(device, W, H, &ctx)) { fail("svgf_create", rc); break; }
+        if (hipMalloc((void **)&rgb, n * 12) != hipSuccess || hipMalloc((void **)&out, n * 12) != hipSuccess ||
+            hipMalloc(&gbuf, n * sizeof(SvgfGBufferTexel)) != hipSuccess || hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) {
+            fail("device buffers", SVGF_ERR_OOM);
+            break;
+        }
+        SvgfParams p;
+        svgf_params_default(&p);
+        p.temporal_enable = 1; p.spatial_enable = 1;          // full SVGF: temporal accumulation + 5 a-trous levels
+        const auto t0 = std::chrono::steady_clock::now();
+        for (int f = 0; f < frames && r->rc == 0; f++) {
+            SvgfCamera cam;
+            SvgfSynthParams sp = { f, 1000 + k, 0.6f, 0.02f, { 0.0f, 0.0f } };      // every context its own sequence (seed)
+            if (int rc = svgf_synth_camera(f, /*moving=*/1, W, H, &cam, sp.pixel_length)) { fail("svgf_synth_camera", rc); break; }
+            if (int rc = svgf_synth_render(device, rgb, gbuf, W, H, &cam, &sp, s)) { fail("svgf_synth_render", rc); break; }
+            if (int rc = svgf_denoise(ctx, out, rgb, gbuf, &cam, &p, s)) { fail("svgf_denoise", rc); break; }   // asynchronous on s
+        }
+        if (r->rc) break;
+        if (int rc = svgf_sync_stream(ctx, s)) { fail("svgf_sync_stream", rc); break; }      // this context's frames only
+        r->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        std::vector<float> h(3 * 64);
+        if (hipMemcpy(h.data(), out + 3 * (n / 2), h.size() * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) { fail("hipMemcpy", SVGF_ERR_HIP); break; }
+        for (float v : h) r->checksum += v;
+    } while (false);
+    if (s) (void)hipStreamDestroy(s);
+    if (rgb) (void)hipFree(rgb);
+    if (out) (void)hipFree(out);
+    if (gbuf) (void)hipFree(gbuf);
+    svgf_destroy(ctx);          // NULL-safe, like denoiseFree
+}
+
+int main(int argc, char **argv)
+{
+    const int n_ctx = argc > 1 ? atoi(argv[1]) : 8, frames = argc > 2 ? atoi(argv[2]) : 64;
+    const int W = argc > 3 ? atoi(argv[3]) : 3840, H = argc > 4 ? atoi(argv[4]) : 2160;
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0) { fprintf(stderr, "farm: no HIP device (the library has no CPU path)\n"); return 2; }
+    if (n_ctx <= 0 || frames <= 0 || W <= 0 || H <= 0) { fprintf(stderr, "usage: farm [contexts] [frames] [width] [height]\n"); return 2; }
+    std::vector<Result> res(n_ctx);
+    std::vector<std::thread> th;
+    for (int k = 0; k < n_ctx; k++) th.emplace_back(run_context, k, k % n_dev, W, H, frames, &res[k]);
+    for (auto &t : th) t.join();
+    double slowest = 0.0;
+    int bad = 0;
+    for (int k = 0; k < n_ctx; k++) {
+        if (res[k].rc) { bad++; printf("context %d device %d FAILED rc %d: %s\n", k, res[k].device, res[k].rc, res[k].err); continue; }
+        printf("context %d device %d frames %d ms_per_frame %.4f checksum %.6f\n", k, res[k].device, frames, res[k].seconds / frames * 1e3, res[k].checksum);
+        if (res[k].seconds > slowest) slowest = res[k].seconds;
+    }
+    if (bad) return 1;
+    printf("farm: %d contexts on %d device(s), %dx%d, %d frames each: %.1f Mpixels/s aggregate (producer + denoiser)\n", n_ctx, n_dev, W, H, frames,
+           (double)n_ctx * frames * W * H / slowest / 1e6);
+    return 0;
+}

@@ -106,6 +106,12 @@ def test_bench_distributed_branch_runs_with_one_rank_on_rccl():
     assert line["metric"].startswith("SVGF Mpixels/s (full pipeline) at 1080p") and line["unit"] == "Mpixels/s"
     assert line["n_gpus"] == 1 and line["steps"] == 5 and line["scaling"] == "weak" and line["value"] > 100
     assert 0 < line["roofline"]["frac"] < 1 and line["config"]["parallelism"] == "replicas1"
+    # the line says which state of the GPU was timed and what it rests on
+    assert line["state"] == "sustained" and line["cold_ms_per_step"] > line["ms_per_step"] > 0
+    assert len(line["per_rank"]) == 1 and line["per_rank"][0]["rank"] == 0 and line["per_rank"][0]["device"] == 0
+    vv = line["roofline"]["valu_view"]
+    assert vv["simd_instruction_active_pmc"] is None or 0.5 < vv["simd_instruction_active_pmc"] <= 1.01      # a PMC record or nothing: never a literal
+    assert "formula" in vv["fp32_tflops_isolated_is"] and "formula" in line["roofline"]["transcendental_gops_isolated_is"]
 
 
 @pytest.mark.gpu
@@ -134,3 +140,8 @@ def test_bench_launcher_two_ranks_sharing_one_gpu():
     px_per_step = 1920 * 1080
     assert abs(line["value"] * 1e6 * line["ms_per_step"] * 1e-3 - 2 * px_per_step) <= 0.01 * 2 * px_per_step
     assert "cpu_baseline" not in line and line["latency_ms_sync"] > 0
+    # one entry per rank: its own clock around its own steps, its device, a CPU slice disjoint from the other rank's
+    pr = line["per_rank"]
+    assert [r_["rank"] for r_ in pr] == [0, 1] and all(r_["device"] == 0 for r_ in pr)
+    assert all(0 < r_["ms_per_step"] <= line["ms_per_step"] * 1.001 for r_ in pr)
+    assert pr[0]["cpus"] and pr[1]["cpus"] and not (set(pr[0]["cpus"]) & set(pr[1]["cpus"])) or len(os.sched_getaffinity(0)) < 2

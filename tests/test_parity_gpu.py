@@ -496,3 +496,57 @@ def test_two_host_threads_two_contexts(pkg):
         for f in range(N):
             assert np.array_equal(both[i][f], alone[i][f]), f"thread {i} frame {f}"
     assert torch.cuda.current_device() == 0
+
+
+def test_eight_host_threads_eight_contexts(pkg):
+    """The shape of the 8-GPU farm inside ONE process, as far as a one-GPU box can take it: eight host threads, each with its own
+    context, stream and sequence (four sizes, so different launch geometries, kernel instantiations and per-device launch caches are
+    hit concurrently for the first time), with per-kernel profiling armed on every context (the profiler hands its event pair to the
+    launcher through a thread-local).  Each thread must get bit for bit what it gets alone; every context reports its own kernels."""
+    import threading
+    import torch
+    sizes = [(960, 540), (480, 270), (1920, 136), (640, 360), (800, 800), (333, 111), (1280, 90), (96, 54)]
+    N = 4
+    p = pkg.reference_defaults().set(temporal_enable=1, spatial_enable=1)
+    frames = [[pkg.synth.render_frame(W, H, f, seed=171 + i, moving=True) for f in range(N)] for i, (W, H) in enumerate(sizes)]
+    dev_frames = [[(torch.from_numpy(c).cuda(), torch.from_numpy(g.view(np.uint8).reshape(-1)).cuda(), cam) for c, g, cam in fr] for fr in frames]
+    start = threading.Barrier(len(sizes))
+
+    def work(i, outs, kinds, errs, together):
+        try:
+            W, H = sizes[i]
+            d = pkg.Denoiser(W, H, 0)
+            d.profile_enable(N)
+            st = torch.cuda.Stream()
+            if together:
+                start.wait()
+            res = []
+            for f in range(N):
+                c, g, cam = dev_frames[i][f]
+                o = torch.empty((H, W, 3), dtype=torch.float32, device="cuda")
+                d.denoise(o, c, g, cam, p, stream=st)
+                res.append(o)
+            d.sync_stream(st)
+            outs[i] = [r.cpu().numpy() for r in res]
+            kinds[i] = [[k for k, ms in d.profile_read(s)] for s in range(N)]
+            assert all(ms > 0 for s in range(N) for k, ms in d.profile_read(s))
+            d.free()
+        except Exception as e:      # noqa: BLE001
+            errs.append((i, e))
+
+    alone, kinds_alone, errs = {}, {}, []
+    for i in range(len(sizes)):
+        work(i, alone, kinds_alone, errs, False)
+    assert not errs, errs
+    both, kinds_both = {}, {}
+    ts = [threading.Thread(target=work, args=(i, both, kinds_both, errs, True)) for i in range(len(sizes))]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errs, errs
+    for i in range(len(sizes)):
+        for f in range(N):
+            assert np.array_equal(both[i][f], alone[i][f]), f"thread {i} ({sizes[i]}) frame {f}"
+        assert kinds_both[i] == kinds_alone[i] and len(kinds_both[i][0]) == 6, f"thread {i}: kernels recorded {kinds_both[i]}"
+    assert torch.cuda.current_device() == 0

@@ -125,3 +125,26 @@ def test_a_captured_pair_of_frames_replays_bit_identically(pkg):
     d.free()
     for f in range(2 * ROUNDS):
         assert np.array_equal(got[f], want[f]), f"frame {f}: graph replay differs from the eager run"
+
+
+def test_cpp_farm_example_eight_contexts_from_one_process(pkg):
+    """examples/farm.cpp: eight contexts (threads, streams) driven from one C++ process through the C ABI, sharing this box's one
+    GPU (context k on device k mod n_devices; on an 8-GPU node: one per GPU).  Every context succeeds, the sequences are
+    independent (eight different checksums), and a context's result does not depend on how many others run beside it."""
+    import os
+    import re
+    import subprocess
+    from conftest import ROOT
+    exe = os.path.join(ROOT, "examples", "farm")
+    assert os.path.exists(exe), "examples/farm is built by __graft_entry__.build()"
+
+    def run(n):
+        r = subprocess.run([exe, str(n), "5", "640", "360"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout
+        cs = {int(m.group(1)): m.group(2) for m in re.finditer(r"context (\d+) device \d+ frames 5 ms_per_frame [0-9.]+ checksum ([-0-9.]+)", r.stdout)}
+        assert len(cs) == n and "Mpixels/s aggregate" in r.stdout, r.stdout
+        return cs
+
+    eight, one = run(8), run(1)
+    assert len(set(eight.values())) == 8, eight
+    assert eight[0] == one[0]

@@ -1,34 +1,125 @@
 #!/usr/bin/env python3
-"""Rebuild profiles/pmc_traffic.json (HBM bytes per a-trous launch, what bench.py reports as roofline.traffic) from a
-pmc_summary.py listing of separate FETCH_SIZE / WRITE_SIZE passes.  usage: pmc_traffic_update.py <pmc_hbm_summary.txt>"""
-import json, os, re, sys
+"""Maintain profiles/pmc_traffic.json — the hashed PMC record bench.py reads `roofline.traffic` and `roofline.valu_view` from.
+
+  pmc_traffic_update.py hbm <pmc_hbm_summary.txt> <WxH>
+      HBM-side bytes per a-trous launch from a tools/pmc_summary.py listing of SEPARATE FETCH_SIZE / WRITE_SIZE passes (as
+      MI355X_MICROARCH.md prescribes: KiB units, FETCH_SIZE doubled — gfx950 tallies 128-byte read requests at 64 bytes).
+  pmc_traffic_update.py sq <pmc_sq_summary.txt> <rocprofv3 kernel_stats.csv> <sclk_mhz> <WxH>
+      SIMD activity of the a-trous launches: SQ_ACTIVE_INST_ANY x 4 / (launch duration x sclk x SIMDs) and the VALU / LDS / scalar
+      shares, SQ_INSTS_VALU per launch.  The duration comes from the kernel-trace summary of the same build, the clock from the
+      telemetry of that run.
+
+Every update stamps the record with bench.kernel_sources_sha16(): bench.py reports the figures only while the kernel sources
+still hash to what the passes ran on."""
+import csv
+import json
+import os
+import re
+import sys
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-px = 1920 * 1080
-f = {}
-for line in open(sys.argv[1]):
-    m = re.search(r"k_atrous_(lane|strip)<(\d).*?(FETCH_SIZE|WRITE_SIZE)\s+n=\s*\d+ median=\s*(\d+)", line)
-    if m:
-        f[(int(m.group(2)), m.group(3))] = (float(m.group(4)) * 1024 / px, m.group(1))
-lv, tot = {}, 0.0
-for L in range(1, 6):
-    fe, wr = 2 * f[(L, "FETCH_SIZE")][0], f[(L, "WRITE_SIZE")][0]        # FETCH_SIZE x2: MI355X_MICROARCH.md, gfx950 correction
-    lv[f"step{1 << L}"] = {"kernel": "k_atrous_" + f[(L, "FETCH_SIZE")][1], "fetch_x2": round(fe, 1), "write": round(wr, 1)}
-    tot += fe + wr
-p = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-d = json.load(open(p))
-d["per_level_bytes_per_pixel"] = lv
-d["mean_bytes_per_pixel_per_launch"] = round(tot / 5, 1)
-d["mean_bytes_per_launch"] = int(tot / 5 * px)
-sys.path.insert(0, ROOT)
-import bench  # noqa: E402  (kernel_sources_sha16: the fingerprint bench.py checks before it reports this record)
-d["kernel_sources_sha16"] = bench.kernel_sources_sha16()
-d["source_file"] = os.path.basename(sys.argv[1]) if len(sys.argv) > 1 else ""
-d["why_above_algorithmic"] = ("4 halo rows per 17-row segment (x1.24 on the 40 B/px read) and 2 halo lattice columns either side of a strip; +4 B/px written by "
-                              "the levels that feed a step-16/32 level its 4-byte variance plane, and 8-12 B/px read from it there (three rows, fetched by the two "
-                              "or three XCDs that hold neighbouring y-phases) instead of ~24 B/px of 4-byte gathers from 16-byte texels")
-d["_comment"] = ("HBM-side traffic of the a-trous kernels (default path at 1920 columns: k_atrous_lane on all five levels) from rocprofv3 "
-                 "PMC, collected as MI355X_MICROARCH.md prescribes: FETCH_SIZE and WRITE_SIZE in separate --pmc passes "
-                 "(profiles/r04_pmc_hbm.txt), KiB units, FETCH_SIZE doubled (gfx950 tallies 128-B read requests at 64 B). "
-                 "Bytes per pixel per launch, 1920x1080.  Reported by bench.py only while kernel_sources_sha16 matches the sources.")
-json.dump(d, open(p, "w"), indent=2)
-print(json.dumps(lv), d["mean_bytes_per_pixel_per_launch"], d["mean_bytes_per_launch"])
+P = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+N_SIMD = 256 * 4
+
+
+def load():
+    try:
+        d = json.load(open(P))
+    except OSError:
+        d = {}
+    if "by_resolution" not in d:        # round 4's flat 1080p record
+        old = {k: d[k] for k in ("per_level_bytes_per_pixel", "mean_bytes_per_pixel_per_launch", "mean_bytes_per_launch",
+                                 "algorithmic_bytes_per_launch", "source_file") if k in d}
+        d = {"by_resolution": {"1920x1080": old} if old else {}, "sq_activity": {}, "kernel_sources_sha16": d.get("kernel_sources_sha16")}
+    d.setdefault("sq_activity", {})
+    return d
+
+
+def stamp(d):
+    sys.path.insert(0, ROOT)
+    import bench  # noqa: E402
+    sha = bench.kernel_sources_sha16()
+    if d.get("kernel_sources_sha16") != sha:      # records measured on other sources are no longer valid beside this one
+        keep = d.pop("_updated_now", set())
+        d["by_resolution"] = {k: v for k, v in d["by_resolution"].items() if ("hbm", k) in keep}
+        d["sq_activity"] = {k: v for k, v in d["sq_activity"].items() if ("sq", k) in keep}
+    d.pop("_updated_now", None)
+    d["kernel_sources_sha16"] = sha
+    d["_comment"] = ("PMC records of the a-trous kernels on the default path (k_atrous_lane on all five levels at 1920 / 3840 columns), rocprofv3, "
+                     "collected as MI355X_MICROARCH.md prescribes: FETCH_SIZE and WRITE_SIZE in separate --pmc passes, KiB units, FETCH_SIZE "
+                     "doubled (gfx950 tallies 128-B read requests at 64 B); SQ counters in their own passes.  bench.py reports them only while "
+                     "kernel_sources_sha16 matches the sources (tools/pmc_traffic_update.py).")
+    json.dump(d, open(P, "w"), indent=2)
+
+
+def level_of(name):
+    m = re.search(r"k_atrous_(lane|strip)<(\d)", name)
+    return (int(m.group(2)), m.group(1)) if m else None
+
+
+def cmd_hbm(path, res):
+    w, h = map(int, res.split("x"))
+    px = w * h
+    f = {}
+    for line in open(path):
+        m = re.search(r"k_atrous_(lane|strip)<(\d).*?(FETCH_SIZE|WRITE_SIZE)\s+n=\s*\d+ median=\s*(\d+)", line)
+        if m:
+            f[(int(m.group(2)), m.group(3))] = (float(m.group(4)) * 1024 / px, m.group(1))
+    lv, tot = {}, 0.0
+    for L in range(1, 6):
+        fe, wr = 2 * f[(L, "FETCH_SIZE")][0], f[(L, "WRITE_SIZE")][0]
+        lv[f"step{1 << L}"] = {"kernel": "k_atrous_" + f[(L, "FETCH_SIZE")][1], "fetch_x2": round(fe, 1), "write": round(wr, 1)}
+        tot += fe + wr
+    d = load()
+    d["by_resolution"][res] = {"per_level_bytes_per_pixel": lv, "mean_bytes_per_pixel_per_launch": round(tot / 5, 1),
+                               "mean_bytes_per_launch": int(tot / 5 * px), "algorithmic_bytes_per_launch": 56 * px,
+                               "ratio_to_algorithmic": round(tot / 5 / 56.0, 3), "source_file": os.path.basename(path)}
+    d["_updated_now"] = {("hbm", res)}
+    stamp(d)
+    print(res, json.dumps(lv), round(tot / 5, 1), "B/px per launch =", round(tot / 5 / 56.0, 3), "x algorithmic")
+
+
+def cmd_sq(path, stats_csv, sclk_mhz, res):
+    cnt = {}
+    for line in open(path):
+        m = re.search(r"k_atrous_(lane|strip)<(\d).*?(SQ_\w+)\s+n=\s*\d+ median=\s*(\d+)", line)
+        if m:
+            cnt.setdefault(int(m.group(2)), {})[m.group(3)] = float(m.group(4))
+    dur = {}
+    for r in csv.DictReader(open(stats_csv)):
+        lv = level_of(r["Name"])
+        if lv and "<" in r["Name"]:
+            m = re.search(r"k_atrous_(lane|strip)<(\d+), (true|false), (\d+), (\d+), (\d+), (\d+)>", r["Name"])
+            if m and (int(m.group(5)), int(m.group(6)), int(m.group(7))) != (0, 0, 0):
+                continue
+            dur[lv[0]] = float(r["AverageNs"]) * 1e-9
+    sclk = float(sclk_mhz) * 1e6
+    out = {}
+    for L in sorted(cnt):
+        if L not in dur or "SQ_ACTIVE_INST_ANY" not in cnt[L]:
+            continue
+        simd_cycles = dur[L] * sclk * N_SIMD
+        c = cnt[L]
+        out[f"step{1 << L}"] = {"simd_instruction_active": round(c["SQ_ACTIVE_INST_ANY"] * 4 / simd_cycles, 3),
+                                "valu_active": round(c.get("SQ_ACTIVE_INST_VALU", 0) * 4 / simd_cycles, 3),
+                                "lds_active": round(c.get("SQ_ACTIVE_INST_LDS", 0) * 4 / simd_cycles, 3),
+                                "scalar_active": round(c.get("SQ_ACTIVE_INST_SCA", 0) * 4 / simd_cycles, 3),
+                                "insts_valu": int(c.get("SQ_INSTS_VALU", 0)), "insts_lds": int(c.get("SQ_INSTS_LDS", 0)),
+                                "insts_salu": int(c.get("SQ_INSTS_SALU", 0)), "launch_us": round(dur[L] * 1e6, 2)}
+    vals = [v["simd_instruction_active"] for v in out.values()]
+    d = load()
+    d["sq_activity"][res] = {"per_level": out, "simd_instruction_active_mean": round(sum(vals) / len(vals), 3) if vals else None,
+                             "formula": "SQ_ACTIVE_INST_ANY x 4 / (launch duration x sclk x 1024 SIMDs)", "sclk_mhz": float(sclk_mhz),
+                             "source_files": [os.path.basename(path), os.path.basename(stats_csv)]}
+    d["_updated_now"] = {("sq", res)}
+    stamp(d)
+    print(res, json.dumps(d["sq_activity"][res]))
+
+
+if __name__ == "__main__":
+    if len(sys.argv) >= 4 and sys.argv[1] == "hbm":
+        cmd_hbm(sys.argv[2], sys.argv[3])
+    elif len(sys.argv) >= 6 and sys.argv[1] == "sq":
+        cmd_sq(sys.argv[2], sys.argv[3], sys.argv[4], sys.argv[5])
+    else:
+        raise SystemExit(__doc__)
