@@ -501,7 +501,7 @@ def main():
             "kernels_us": {"temporal": round(float(np.mean(temporal_ms)) * 1e3, 2) if temporal_ms else None,
                            "fused_prepare_plus_level1": round(float(np.mean(fused_ms)) * 1e3, 2) if fused_ms else None,
                            "atrous_level_mean": round(a_ms * 1e3, 2), "atrous_launches_per_frame": round(len(atrous_ms) / max(1, len(fused_ms) + len(temporal_ms)), 2) if (fused_ms or temporal_ms) else None},
-            "frame_algorithmic_gbs": round((ATROUS_BYTES_PER_PIXEL if a.config == "config1" else FRAME_BYTES_PER_PIXEL)
+            "frame_algorithmic_gbs": round((bytes_px if a.config == "config1" else FRAME_BYTES_PER_PIXEL)
                                            * W * H / (dt / a.steps) / 1e9 / world * 1.0, 1),
         }
         if world == 1 and not a.no_cpu_baseline and a.config in ("1080p-static", "config1"):

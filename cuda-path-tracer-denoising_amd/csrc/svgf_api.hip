@@ -593,7 +593,7 @@ static int denoise_frame(svgf_ctx *c, void *out_rgb_dev, const void *in_rgb_dev,
 #endif
         t.skip_split = split_fused ? 1 : 0;
         if (!fused) {
-            LAUNCH(SVGF_KERNEL_TEMPORAL, launch_temporal(t, s, false));
+            LAUNCH(SVGF_KERNEL_TEMPORAL, launch_temporal(t, s));
             if (p->spatial_variance_frames > 0)      // f4 extension: spatial variance estimate for short histories (its own profiling slot, same kind)
                 LAUNCH(SVGF_KERNEL_TEMPORAL, launch_spatial_variance(c->cv[acc], c->mom[1 - c->cur], c->hlen[1 - c->cur], c->nrm[gnew], c->gid[gnew],
                                                                      c->W, c->H, p->spatial_variance_frames, s));

@@ -129,7 +129,7 @@ struct TemporalArgs {
                               // loaders will: svgf_atrous_fused.hip, FUSED = 4)
 };
 
-hipError_t launch_temporal(const TemporalArgs &a, hipStream_t s, bool single_wave_blocks);
+hipError_t launch_temporal(const TemporalArgs &a, hipStream_t s);
 // SvgfParams::spatial_variance_frames (f4): variance of short-history pixels from the 7x7 neighbourhood's moments
 hipError_t launch_spatial_variance(float4 *cv_acc, const float2 *mom_acc, const int *hlen_upd, const float *nrm, const int *gid,
                                    int W, int H, int K, hipStream_t s);

@@ -127,13 +127,10 @@ __global__ __launch_bounds__(BLOCK) void k_temporal(TemporalArgs a)
     a.cv_acc[p] = o.cv;
 }
 
-hipError_t launch_temporal(const TemporalArgs &a, hipStream_t s, bool single_wave_blocks)
+hipError_t launch_temporal(const TemporalArgs &a, hipStream_t s)
 {
     const long long n = (long long)a.W * a.H;
-    // When this pass runs beside an a-trous launch (cross-frame overlap) only single free wave slots exist on a CU:
-    // one-wave workgroups can be placed in them, four-wave workgroups cannot.
-    if (single_wave_blocks) SVGF_LAUNCH_KERNEL(k_temporal<64>, dim3(div_up(n, 64)), dim3(64), 0, s, a);
-    else SVGF_LAUNCH_KERNEL(k_temporal<SVGF_BLOCK>, dim3(div_up(n, SVGF_BLOCK)), dim3(SVGF_BLOCK), 0, s, a);
+    SVGF_LAUNCH_KERNEL(k_temporal<SVGF_BLOCK>, dim3(div_up(n, SVGF_BLOCK)), dim3(SVGF_BLOCK), 0, s, a);
     return hipGetLastError();
 }
 

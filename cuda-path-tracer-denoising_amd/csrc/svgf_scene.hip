@@ -246,11 +246,18 @@ static int scene_render_impl(int device, void *out_rgb_dev, void *out_gbuffer_de
     // usually pageable, often temporaries of a binding, and must have been read when this function returns) without waiting for
     // whatever else is queued on `s` — the previous frame's whole denoise, typically — and without a host synchronisation on a
     // stream that may be under capture.  The kernel and the release of the staging memory stay asynchronous on `s`.
+    // (one per device, created on first use under a lock and kept for the life of the process; a creation that fails is not
+    // remembered — the next call tries again — and a device index outside the table is refused rather than folded onto slot 0,
+    // whose stream belongs to another device)
     static hipStream_t up_streams[64];
-    static std::once_flag up_once[64];
-    const int dslot = (device >= 0 && device < 64) ? device : 0;
-    std::call_once(up_once[dslot], [&]() { if (hipStreamCreateWithFlags(&up_streams[dslot], hipStreamNonBlocking) != hipSuccess) up_streams[dslot] = nullptr; });
-    hipStream_t up = up_streams[dslot];
+    static std::mutex up_mutex;
+    if (device < 0 || device >= 64) return SVGF_ERR_UNSUPPORTED;
+    hipStream_t up = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(up_mutex);
+        if (!up_streams[device] && hipStreamCreateWithFlags(&up_streams[device], hipStreamNonBlocking) != hipSuccess) up_streams[device] = nullptr;
+        up = up_streams[device];
+    }
     if (!up) return SVGF_ERR_HIP;
     char *d = nullptr;
     if (hipMallocAsync(reinterpret_cast<void **>(&d), o_tex + b_tex, up) != hipSuccess) return SVGF_ERR_OOM;

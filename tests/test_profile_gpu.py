@@ -8,6 +8,7 @@ import threading
 
 import numpy as np
 import pytest
+from conftest import relerr
 
 pytestmark = pytest.mark.gpu
 
@@ -94,6 +95,5 @@ def test_two_threads_one_profiled_one_not(pkg, orc):
         t.join()
     for tag in ("a", "b"):
         for f in range(len(frames)):
-            den = np.maximum(np.abs(ref[f]), 1e-3)
-            assert (np.abs(res[tag][0][f] - ref[f]) / den).max() <= 1e-5, f"thread {tag} frame {f}"
+            assert relerr(res[tag][0][f], ref[f]).max() <= 1e-5, f"thread {tag} frame {f}"
     assert res["a"][1] == [6] * len(frames), res["a"][1]

@@ -320,7 +320,7 @@ def test_room_1080p_moving_64_frames_device_producer_to_denoiser_vs_oracle(pkg, 
         err = relerr(got, ref)
         worst.append(float(err.max()))
         assert err.max() <= 1e-4, f"frame {f}: max rel {err.max():.3e}"
-    print(f"room 1920x1080, 64 moving frames: worst max-rel {max(worst):.2e} (first 8: {max(worst[:8]):.2e}, last 8: {max(worst[-8:]):.2e})")
+    print(f"BASELINE configs[2] (room.txt 1920x1080, 64 moving frames, full SVGF) vs oracle: worst max-rel {max(worst):.2e} (first 8: {max(worst[:8]):.2e}, last 8: {max(worst[-8:]):.2e})")
     den.free(); o.free()
 
 
@@ -341,6 +341,7 @@ def test_bunny_4k_static_device_producer_to_denoiser_vs_oracle(pkg, orc):
     rgb = torch.empty((H, W, 3), dtype=torch.float32, device="cuda")
     gbt = torch.empty((H * W * 52,), dtype=torch.uint8, device="cuda")
     out = torch.empty((H, W, 3), dtype=torch.float32, device="cuda")
+    worst = 0.0
     for f in range(N):
         cam = pkg.scene.camera_for_frame(sc, f, False)
         pkg.binding.scene_render_mesh(rgb, gbt, W, H, cam, pi["geoms"], pi["geom_ids"], pi["tris"], pi["tri_ids"], pi["tri_albedo"], frame=f)
@@ -355,7 +356,9 @@ def test_bunny_4k_static_device_producer_to_denoiser_vs_oracle(pkg, orc):
         got = out.cpu().numpy()
         err = relerr(got, ref)
         assert err.max() <= 1e-4, f"frame {f}: max rel {err.max():.3e}"
+        worst = max(worst, float(err.max()))
     den.free(); o.free()
+    print(f"BASELINE configs[3] (bunny.txt 3840x2160, full SVGF, 2 frames) vs oracle: worst max-rel {worst:.2e}")
 
 
 @pytest.mark.gpu
@@ -389,5 +392,5 @@ def test_room_4k_static_device_producer_to_denoiser_vs_oracle(pkg, orc):
         err = relerr(out.cpu().numpy(), ref)
         worst = max(worst, float(err.max()))
         assert err.max() <= 1e-4, f"frame {f}: max rel {err.max():.3e}"
-    print(f"room 3840x2160, 2 static frames: worst max-rel {worst:.2e}")
+    print(f"BASELINE configs[4], one GPU's share (room.txt 3840x2160, full SVGF, 2 frames) vs oracle: worst max-rel {worst:.2e}")
     den.free(); o.free()
