@@ -121,6 +121,19 @@ int main(int argc, char **argv)
                "E five empty launches %.2f us (%.2f each) | boundary - barrier = %.2f us per level\n",
                r, a, a / 5, a / 5 - T_us, b, b / 5, b / 5 - T_us, e, e / 5, (a - b) / 4);
     }
+    // what the 2.6 us of an empty launch are made of: the same empty kernel in other shapes (256 workgroups each)
+    struct Shape { int threads; size_t lds; const char *what; } shapes[] = {
+        { 64, 0, "64 threads, no LDS" }, { 256, 0, "256 threads, no LDS" }, { 768, 0, "768 threads, no LDS" },
+        { 768, 64 * 1024, "768 threads, 64 KB LDS" }, { 768, kLds, "768 threads, 148 KB LDS (the lane kernel's shape)" } };
+    for (const Shape &sh : shapes) {
+        for (int r = 0; r < 2; r++) {
+            CK(hipEventRecord(e0, s));
+            for (int f = 0; f < 2000; f++) hipLaunchKernelGGL(k_empty, dim3(NB), dim3(sh.threads), sh.lds, s, p0);
+            CK(hipEventRecord(e1, s)); CK(hipEventSynchronize(e1));
+            float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+            if (r == 1) printf("empty launch, 256 workgroups x %s: %.2f us each (2000 back to back)\n", sh.what, (double)ms * 1e3 / 2000);
+        }
+    }
     CK(hipDeviceSynchronize());
     return 0;
 }
