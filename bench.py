@@ -184,10 +184,13 @@ def main():
                          "--config 4k-room`; config1 = configs[0]: 800x800, temporal off, one a-trous level, CPU leg single-threaded")
     ap.add_argument("--kernel-variant", type=int, default=0,
                     help="SvgfParams::kernel_variant (0 = the library's default choice; 2 strip, 4 lane-marching kernel ...)")
-    ap.add_argument("--overlap", action="store_true",
-                    help="no effect since round 4: SvgfParams::inputs_ready is accepted and ignored (the cross-frame overlap lost 3-8 %% "
-                         "in round 3 and the fused first level removed the pass it hid); kept so that old command lines still run")
-    ap.add_argument("--no-overlap", action="store_true", help="(no effect; kept so that old command lines still run)")
+    ap.add_argument("--no-pipeline", action="store_true",
+                    help="order every frame on the one stream (SvgfParams::inputs_ready = 0).  Default: the frame pipeline (ABI 0.8) — "
+                         "the inputs of this benchmark are resident and two output buffers alternate, which is what inputs_ready "
+                         "promises; consecutive frames then run on two internal streams (frame n's levels 2-5 beside frame n+1's "
+                         "temporal pass + level 1), bit-identical results")
+    ap.add_argument("--overlap", action="store_true", help="(old name of the default; kept so that old command lines still run)")
+    ap.add_argument("--no-overlap", action="store_true", help="same as --no-pipeline")
     ap.add_argument("--latency-calls", type=int, default=60,
                     help="svgf_denoise + svgf_sync pairs of the latency measurement (SURVEY.md 8(d)(i): median of >= 50 after 10 warm-ups)")
     ap.add_argument("--host-inputs", action="store_true",
@@ -268,6 +271,8 @@ def main():
     params.set(kernel_variant=a.kernel_variant)
     if a.config == "config1":   # BASELINE configs[0]: the reference's own CPU-runnable case
         params.set(temporal_enable=0, atrous_nlevel=1)
+    pipeline = not (a.no_pipeline or a.no_overlap or a.planar_inputs)      # (the planar path orders its frames: the library ignores the promise there)
+    params.set(inputs_ready=1 if pipeline else 0)
 
     # every rank owns one independent sequence (its own seed); 4 distinct noisy frames, static camera, resident in HBM
     seq = pkg.farm.shard(world, world, rank)[0]
@@ -302,7 +307,8 @@ def main():
         torch.cuda.synchronize(dev)
         frames = None
     cams = [pkg.SvgfCamera.from_dict(c) for c in cam_dicts]
-    out = torch.empty((H, W, 3), dtype=torch.float32, device=dev)
+    outs = [torch.empty((H, W, 3), dtype=torch.float32, device=dev) for _ in range(2)]      # alternate: frame n+1 may write while frame n still does
+    out = outs[0]
     den = pkg.Denoiser(W, H, device=local_rank)
     stream = torch.cuda.current_stream(dev)
     PROFILE_STRIDE = 10     # an event pair attached to every kernel dispatch of every 10th timed step (a timed frame runs ~25 us longer)
@@ -322,7 +328,7 @@ def main():
         if a.planar_inputs:
             den.denoise_planar(out, d_in[k], cams[k], params, stream=stream)
         else:
-            den.denoise(out, d_in[k], d_g[k], cams[k], params, stream=stream)
+            den.denoise(outs[i & 1], d_in[k], d_g[k], cams[k], params, stream=stream)
         return W * H
 
     # Clock / power / temperature sampler (tools/telemetry.py): created and started BEFORE the warm-up.  Finding its hwmon node
@@ -388,8 +394,30 @@ def main():
         lat.append(time.perf_counter() - t0)
     t_lat1 = time.perf_counter()
     lat_ms = np.asarray(lat) * 1e3
-    if not np.isfinite(out.sum().item()):
+    if not (np.isfinite(outs[0].sum().item()) and np.isfinite(outs[1].sum().item())):
         raise SystemExit("bench: non-finite output")
+
+    # the same K steps with every frame ORDERED on the stream (no promise), behind its own sustained warm-up: what the pipeline buys
+    # (a second context that never becomes pipelined: an ordered frame of a pipelined context pays the pipeline's events as well)
+    ordered_ms = None
+    pipeline = pipeline and den.is_pipelined()      # the library takes the promise up only where frames have something to overlap
+    if pipeline:
+        op = pkg.SvgfParams.from_buffer_copy(params).set(inputs_ready=0)
+        den_o = pkg.Denoiser(W, H, device=local_rank)
+        t_o = time.perf_counter()
+        i = 0
+        while time.perf_counter() - t_o < 0.4:
+            den_o.denoise(outs[i & 1], d_in[i % nsrc], d_g[i % nsrc], cams[i % nsrc], op, stream=stream)
+            i += 1
+            if i % 32 == 0:
+                torch.cuda.synchronize(dev)
+        torch.cuda.synchronize(dev)
+        t_o = time.perf_counter()
+        for i in range(a.steps):
+            den_o.denoise(outs[i & 1], d_in[i % nsrc], d_g[i % nsrc], cams[i % nsrc], op, stream=stream)
+        torch.cuda.synchronize(dev)
+        ordered_ms = (time.perf_counter() - t_o) / a.steps * 1e3
+        den_o.free()
 
     # the same kernels with EVERY launch of 16 consecutive frames timed (outside the timed region, sustained clock state)
     iso_params = pkg.reference_defaults().set(temporal_enable=1, spatial_enable=1, atrous_nlevel=NLEVEL, history_level=1)
@@ -456,6 +484,11 @@ def main():
             # which state of the GPU the K timed steps ran in: "sustained" = directly behind >= min_warmup_seconds of
             # back-to-back frames; `cold_ms_per_step` = the first 12 frames of this process (rank 0), for comparison
             "state": "sustained", "sustained_after_s": round(t_warm_end - t_c0, 3), "cold_ms_per_step": round(cold_ms, 5),
+            # the frame pipeline (SvgfParams::inputs_ready, include/svgf.h): consecutive frames of the sequence on two internal streams.
+            # `ordered`: the same K steps of this process with every frame ordered on the one stream (round 4's way; rank 0)
+            "frame_pipeline": pipeline,
+            "ordered": ({"ms_per_step": round(ordered_ms, 5), "value": round(W * H / ordered_ms / 1e3, 2), "unit": "Mpixels/s",
+                         "what": "the same steps on a second context with SvgfParams::inputs_ready = 0 (every frame ordered on the one stream), after their own 0.4 s of warm-up; rank 0"} if ordered_ms else None),
             "per_rank": per_rank,
             # one svgf_denoise + svgf_sync, median of the calls below (host wall clock around the pair)
             "latency_ms_sync": round(float(np.median(lat_ms)), 5),
@@ -481,8 +514,13 @@ def main():
                          "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, profiles/pmc_traffic.json (FETCH x2 per MI355X_MICROARCH.md)",
                          "kernel": "one a-trous level: k_atrous_lane (steps 2-32; k_atrous_strip where the library's cost model prefers it), mean over the level launches of the timed frames; in config1 the one launch per frame that carries the prepare pass in its loader waves", "bytes_per_launch": bytes_px * W * H, "bytes_per_pixel": bytes_px,
                          "mean_launch_us": round(a_ms * 1e3, 2), "launches_timed": len(atrous_ms),
+                         # with the frame pipeline the kernels of two consecutive frames share the GPU: a launch of the timed region
+                         # lasts longer than the same launch alone ('isolated' below: ordered frames), while more than one is in flight
+                         "kernels_in_flight_mean": round((sum(atrous_ms) + sum(temporal_ms) + sum(fused_ms)) / max(1, len(temporal_ms) + len(fused_ms)) / (dt / a.steps * 1e3), 3)
+                                                   if (temporal_ms or fused_ms) else None,
                          "launch_includes_fused_prepare_pass": level_is_fused,
-                         "note": "everything ordered on one stream; durations are the dispatches' own begin / end timestamps (HIP events attached by hipExtLaunchKernelGGL on the launch stream, every 10th timed frame); 'isolated' repeats the measurement on every kernel of 16 frames",
+                         "note": ("frame pipeline on: the kernels of consecutive frames overlap, 'achieved' / 'frac' are the launches of the timed region as they ran (sharing the GPU); " if pipeline else "everything ordered on one stream; ")
+                                 + "durations are the dispatches' own begin / end timestamps (HIP events attached by hipExtLaunchKernelGGL on the launch stream, every 10th timed frame); 'isolated' repeats the measurement on every kernel of 16 ORDERED frames (one kernel at a time on the GPU: the kernel's own speed)",
                          "isolated": {"mean_launch_us": round(iso_us, 2), "achieved": round(iso_gbs, 1),
                                       "frac": round(iso_gbs / HBM_PEAK_GBS, 4), "launches_timed": len(iso_atrous_ms)},
                          # the secondary limiter.  24 taps x (2 v_sqrt + 1 v_exp) + 5 (centre, normalisation) per pixel-level

@@ -31,7 +31,7 @@ EXPORTS = ["svgf_version", "svgf_params_default", "svgf_create", "svgf_destroy",
            "svgf_set_capture", "svgf_profile_enable", "svgf_profile_stride", "svgf_profile_frames", "svgf_profile_read",
            "svgf_synth_camera", "svgf_synth_render", "svgf_scene_render", "svgf_scene_render_mesh", "svgf_display_pack", "svgf_save_png",
            "svgf_planar_gbuffer", "svgf_denoise_planar", "svgf_synth_render_planar", "svgf_params_sizeof", "svgf_scene_render_mesh_planar",
-           "svgf_sync_stream", "svgf_build_has_experiments"]
+           "svgf_sync_stream", "svgf_build_has_experiments", "svgf_is_pipelined"]
 
 
 class SvgfCamera(C.Structure):
@@ -149,6 +149,8 @@ def load_library(path: str | None = None, experiments: bool = False):
     lib.svgf_denoise_host.argtypes = [vp, vp, vp, vp, C.POINTER(SvgfCamera), C.POINTER(SvgfParams)]
     lib.svgf_sync.argtypes = [vp]
     lib.svgf_sync_stream.argtypes = [vp, vp]
+    lib.svgf_is_pipelined.argtypes = [vp]
+    lib.svgf_is_pipelined.restype = ip
     lib.svgf_last_error.argtypes = [vp]
     lib.svgf_last_error.restype = C.c_char_p
     lib.svgf_width.argtypes = [vp]
@@ -265,6 +267,10 @@ class Denoiser:
 
     def sync(self):
         self._check(self.lib.svgf_sync(self.h), "svgf_sync")
+
+    def is_pipelined(self) -> bool:
+        """True once a frame with SvgfParams.inputs_ready has switched the context to the frame pipeline (include/svgf.h, ABI 0.8)."""
+        return bool(self.lib.svgf_is_pipelined(self.h))
 
     def sync_stream(self, stream=None):
         """Wait for what has been enqueued on `stream` only (svgf_sync waits for the whole device, as the reference does)."""

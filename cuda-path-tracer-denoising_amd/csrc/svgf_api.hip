@@ -31,9 +31,24 @@ static const bool kSplitFusedByDefault = false;
 struct svgf_ctx {
     int device, W, H;
     size_t n;
-    float4 *cv[3];         // colour + variance planes: history, source, destination of a level (roles rotate)
-    float *vp[3];          // zero-margined (W+2) x (H+2) copies of cv[k].w: what the step-16/32 levels take their 3x3 variance pre-blur from
+    float4 *cv[6];         // colour + variance planes: history, source, destination of a level (roles rotate).  [3..5]: the second
+                           // set of a PIPELINED context (see `pipelined`), allocated when the first frame asks for it
+    float *vp[6];          // zero-margined (W+2) x (H+2) copies of cv[k].w: what the step-16/32 levels take their 3x3 variance pre-blur from
     unsigned vp_valid;     // bit k: vp[k] holds the variance of cv[k]
+    // Frame pipeline (SvgfParams::inputs_ready, round 5).  A frame's temporal pass needs of the previous frame only what exists
+    // once the level feeding the colour history has run (level 1 with the reference's defaults); levels 2-5 of frame n and the
+    // temporal pass + level 1 of frame n+1 are independent.  A pipelined context runs even frames on pipe[0] with planes 0-2 and
+    // odd frames on pipe[1] with planes 3-5; ev_hist[q] (recorded behind the level that writes the history of a frame of parity q)
+    // is all that the other stream's next temporal pass waits for, and the caller's stream waits for ev_done[q] at the end of the
+    // call.  The kernels of two consecutive frames then share the chip: one frame's level tails, launch gaps and opening bursts
+    // lie under the other's tap rows (two INDEPENDENT sequences on two streams: +9-10 % in aggregate,
+    // profiles/r05_exp_two_sequences.log — the ceiling of this).
+    int pipelined;
+    hipStream_t pipe[2];
+    hipEvent_t ev_hist[2], ev_done[2], ev_in;
+    int ev_hist_valid[2];
+    unsigned long long ev_hist_cap[2];      // the stream-capture id ev_hist[q] was last recorded under (0: eagerly)
+    long long pipe_frames;     // frames since the context became pipelined (parity = stream and plane set)
     int use_vplane;        // 0 only for A/B measurements (experiments build: svgf_exp_set("no_variance_plane", 1) before svgf_create)
     void *dump;            // 4 KB of scrap for the fused kernel (TemporalArgs::dump)
     char *arena;           // the one allocation cv[], nrm[], gid[], mom[], hlen[], pos[] and dump are carved from
@@ -191,7 +206,14 @@ static void *plane_carve(svgf_ctx *c, size_t *cursor, size_t bytes)
 static void free_all(svgf_ctx *c)
 {
     if (c->arena) (void)hipFree(c->arena);          // cv[], nrm[], gid[], mom[], hlen[], pos[], dump
-    for (int k = 0; k < 3; k++) if (c->vp[k]) (void)hipFree(c->vp[k]);
+    for (int k = 0; k < 6; k++) if (c->vp[k]) (void)hipFree(c->vp[k]);
+    for (int k = 3; k < 6; k++) if (c->cv[k]) (void)hipFree(reinterpret_cast<char *>(c->cv[k]) - kPlanePad);
+    for (int q = 0; q < 2; q++) {
+        if (c->pipe[q]) (void)hipStreamDestroy(c->pipe[q]);
+        if (c->ev_hist[q]) (void)hipEventDestroy(c->ev_hist[q]);
+        if (c->ev_done[q]) (void)hipEventDestroy(c->ev_done[q]);
+    }
+    if (c->ev_in) (void)hipEventDestroy(c->ev_in);
     for (int k = 0; k < 2; k++) if (c->tp[k]) (void)hipFree(c->tp[k]);
     if (c->albedo) (void)hipFree(c->albedo);
     if (c->cv_capture) (void)hipFree(c->cv_capture);
@@ -206,9 +228,10 @@ static void free_all(svgf_ctx *c)
 
 static int zero_state(svgf_ctx *c)
 {
-    for (int k = 0; k < 3; k++) if (c->cv[k]) HIPC(c, hipMemset(c->cv[k], 0, c->n * sizeof(float4)));
-    for (int k = 0; k < 3; k++) if (c->vp[k]) HIPC(c, hipMemset(c->vp[k], 0, (size_t)(c->W + 2) * (c->H + 2) * sizeof(float) + 64));
+    for (int k = 0; k < 6; k++) if (c->cv[k]) HIPC(c, hipMemset(c->cv[k], 0, c->n * sizeof(float4)));
+    for (int k = 0; k < 6; k++) if (c->vp[k]) HIPC(c, hipMemset(c->vp[k], 0, (size_t)(c->W + 2) * (c->H + 2) * sizeof(float) + 64));
     c->vp_valid = 0;
+    c->pipe_frames = 0; c->ev_hist_valid[0] = c->ev_hist_valid[1] = 0; c->ev_hist_cap[0] = c->ev_hist_cap[1] = 0;      // (a pipelined context stays pipelined)
     for (int k = 0; k < 2; k++) {
         HIPC(c, hipMemset(c->nrm[k], 0, c->n * 3 * sizeof(float)));
         HIPC(c, hipMemset(c->gid[k], 0, c->n * sizeof(int)));
@@ -314,6 +337,8 @@ extern "C" int svgf_reset(svgf_ctx *c)
     HIPC(c, hipDeviceSynchronize());
     return zero_state(c);
 }
+
+extern "C" int svgf_is_pipelined(const svgf_ctx *c) { return (c && c->pipelined) ? 1 : 0; }
 
 extern "C" int svgf_sync(svgf_ctx *c)
 {
@@ -463,6 +488,36 @@ thread_local SvgfLaunchEvents g_svgf_launch_events = { nullptr, nullptr };
 
 // ---- the frame ------------------------------------------------------------------------------------------------
 
+// First frame that asks for the pipeline: the second plane set, two streams, the events.  Allocates and synchronises the device,
+// once per context (not under stream capture: the caller of denoise_frame checks).
+static int ensure_pipeline(svgf_ctx *c)
+{
+    if (c->pipelined) return SVGF_OK;
+    for (int k = 3; k < 6; k++) {
+        char *raw = nullptr;
+        if (!c->cv[k]) {
+            if (hipMalloc((void **)&raw, c->n * sizeof(float4) + 2 * kPlanePad) != hipSuccess) { snprintf(c->err, sizeof(c->err), "svgf_denoise: hipMalloc failed for the pipeline's planes"); return SVGF_ERR_OOM; }
+            c->cv[k] = reinterpret_cast<float4 *>(raw + kPlanePad);
+            HIPC(c, hipMemset(raw, 0, c->n * sizeof(float4) + 2 * kPlanePad));
+        }
+        if (!c->vp[k]) {
+            const size_t vb = (size_t)(c->W + 2) * (c->H + 2) * sizeof(float) + 64;
+            if (hipMalloc((void **)&c->vp[k], vb) != hipSuccess) { snprintf(c->err, sizeof(c->err), "svgf_denoise: hipMalloc failed for the pipeline's planes"); return SVGF_ERR_OOM; }
+            HIPC(c, hipMemset(c->vp[k], 0, vb));
+        }
+    }
+    for (int q = 0; q < 2; q++) {
+        if (!c->pipe[q]) HIPC(c, hipStreamCreateWithFlags(&c->pipe[q], hipStreamNonBlocking));
+        if (!c->ev_hist[q]) HIPC(c, hipEventCreateWithFlags(&c->ev_hist[q], hipEventDisableTiming));
+        if (!c->ev_done[q]) HIPC(c, hipEventCreateWithFlags(&c->ev_done[q], hipEventDisableTiming));
+    }
+    if (!c->ev_in) HIPC(c, hipEventCreateWithFlags(&c->ev_in, hipEventDisableTiming));
+    HIPC(c, hipDeviceSynchronize());
+    c->pipelined = 1;
+    c->pipe_frames = 0; c->ev_hist_valid[0] = c->ev_hist_valid[1] = 0;
+    return SVGF_OK;
+}
+
 // Auto selection between the two fast a-trous kernels for steps 2-32.  The lane-marching kernel works on 480-column strips (at
 // steps 16 / 32: 120 / 60 lattice columns of 4 / 8 x-phases), the strip kernel on 256-column strips; both cut the image into
 // (strip, y-phase, segment) workgroups that run in rounds of one per CU, and both know what their launch will cost:
@@ -538,7 +593,38 @@ static int denoise_frame(svgf_ctx *c, void *out_rgb_dev, const void *in_rgb_dev,
     }
     SvgfDeviceGuard dev_guard(c->device);
     if (!dev_guard.ok) { snprintf(c->err, sizeof(c->err), "hipSetDevice(%d) failed", c->device); return SVGF_ERR_HIP; }
-    hipStream_t s = (hipStream_t)stream;
+    hipStream_t s_user = (hipStream_t)stream;
+    // Pipelined frames (see svgf_ctx::pipelined).  The promise behind inputs_ready: at call time the inputs are complete, nothing
+    // enqueued earlier on `stream` still reads `out`, and both stay untouched until the work of this call is done — so the frame need
+    // not order itself behind the caller's stream (which has waited for the PREVIOUS frame's end).  Without the promise a frame of a
+    // pipelined context waits for the caller's stream position first; under stream capture nothing is promised (the internal stream
+    // joins the capture through that wait).  The planar path and the experiments build's fused temporal pass stay ordered.
+    // (The promise is a permission: it is used where there is something to overlap — a temporal pass and a cascade of two or more
+    // levels.  A one-launch frame like BASELINE configs[0] loses more to the four cross-stream events of a pipelined frame than it
+    // can gain: 0.0247 -> 0.0342 ms measured, profiles/r05_exp_pipeline.log.)
+    bool promise = (p->inputs_ready != 0) && gbuffer_dev != nullptr && p->temporal_enable && p->spatial_enable && p->atrous_nlevel >= 2 &&
+                   p->right_view_option != 1 && p->right_view_option != 2;
+    unsigned long long cap_id = 0;      // != 0: `stream` is being captured into a graph
+    if (promise || c->pipelined) {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        unsigned long long id = 0;
+        if (s_user && hipStreamGetCaptureInfo(s_user, &cs, &id) == hipSuccess && cs != hipStreamCaptureStatusNone) { cap_id = id ? id : 1; promise = false; }
+        // a frame recorded into a graph did not run when it was recorded: the eager frames behind it order themselves behind the
+        // caller's stream (where the graph is launched) until both parities' events are eager ones again
+        if (!cap_id && (c->ev_hist_cap[0] || c->ev_hist_cap[1])) promise = false;
+    }
+#ifdef SVGF_BUILD_EXPERIMENTS
+    if (p->kernel_variant == 6 || p->kernel_variant == 5 || c->use_reuse || c->use_split_fused) promise = false;
+#endif
+    if (promise && !c->pipelined) { const int rc = ensure_pipeline(c); if (rc != SVGF_OK) return rc; }
+    const bool piped = c->pipelined != 0;
+    const int pq = piped ? (int)(c->pipe_frames & 1) : 0;
+    const int pbase = piped ? 3 * pq : 0;          // this frame's plane set
+    hipStream_t s = piped ? c->pipe[pq] : s_user;
+    if (piped && (!promise || c->pipe_frames == 0)) {      // ordered behind what the caller's stream holds (always: the first pipelined frame)
+        HIPC(c, hipEventRecord(c->ev_in, s_user));
+        HIPC(c, hipStreamWaitEvent(s, c->ev_in, 0));
+    }
     float *out = (float *)out_rgb_dev;
     const float *in = (const float *)in_rgb_dev;
     const float *g = (const float *)gbuffer_dev;
@@ -558,7 +644,13 @@ static int denoise_frame(svgf_ctx *c, void *out_rgb_dev, const void *in_rgb_dev,
     //    (SvgfParams::inputs_ready, the cross-frame overlap of rounds 1-3, is accepted and ignored: it lost 3-8 % once the
     //    lane kernel ran all five levels, and the fusion removes the pass it used to hide.)
     const int old_hist = c->hist;
-    const int acc = (old_hist + 1) % 3;
+    const int acc = piped ? (pbase == old_hist ? pbase + 1 : pbase) : (old_hist + 1) % 3;
+    // the other stream's frame: this frame's temporal pass (and everything behind it) starts when that frame's colour history,
+    // moments, history lengths and G-buffer planes are final
+    // (an event recorded under another capture, or eagerly while this frame is captured, or vice versa, is not waited for: such
+    // frames are ordered through the caller's stream, see above)
+    if (piped && c->ev_hist_valid[1 - pq] && c->ev_hist_cap[1 - pq] == cap_id) HIPC(c, hipStreamWaitEvent(s, c->ev_hist[1 - pq], 0));
+    bool hist_event_recorded = false;
     const int gnew = 1 - c->gcur;
     const bool cascade = !(p->right_view_option == 1 || p->right_view_option == 2 || p->atrous_nlevel == 0 || !p->spatial_enable);
     TemporalArgs t;
@@ -636,7 +728,7 @@ static int denoise_frame(svgf_ctx *c, void *out_rgb_dev, const void *in_rgb_dev,
             int dst = -1;
             if (!last || keep) {
                 // (the fused level reads the OLD colour history while it writes: its destination is the third plane)
-                for (int k = 0; k < 3; k++) if (k != src && k != c->hist && !(fuse_here && k == old_hist)) { dst = k; break; }
+                for (int k = pbase; k < pbase + 3; k++) if (k != src && k != c->hist && !(fuse_here && k == old_hist)) { dst = k; break; }
             }
             AtrousArgs a;
             a.src = c->cv[src]; a.dst = dst >= 0 ? c->cv[dst] : nullptr; a.out_rgb = last ? out : nullptr;
@@ -729,10 +821,23 @@ static int denoise_frame(svgf_ctx *c, void *out_rgb_dev, const void *in_rgb_dev,
             default:        LAUNCH(SVGF_KERNEL_ATROUS, launch_atrous_gather(a, s)); break;
             }
             if (keep) c->hist = dst;
+            if (piped && keep && !hist_event_recorded) {
+                // everything the NEXT frame's temporal pass reads of this frame is final: the other stream may go on
+                HIPC(c, hipEventRecord(c->ev_hist[pq], s));
+                c->ev_hist_valid[pq] = 1; c->ev_hist_cap[pq] = cap_id; hist_event_recorded = true;
+            }
             src = dst;
         }
     }
 
+    if (piped) {
+        // (frames whose history is not the output of a level of the cascade — debug views, pass-through, history_level 0 or beyond
+        // the last level — release the next frame at their end: they read state the next temporal pass rewrites)
+        if (!hist_event_recorded) { HIPC(c, hipEventRecord(c->ev_hist[pq], s)); c->ev_hist_valid[pq] = 1; c->ev_hist_cap[pq] = cap_id; }
+        HIPC(c, hipEventRecord(c->ev_done[pq], s));
+        HIPC(c, hipStreamWaitEvent(s_user, c->ev_done[pq], 0));      // what the caller enqueues behind this call sees `out`
+        c->pipe_frames++;
+    }
     // 3) history rotation (:396-399): planes swap roles instead of being copied
     if (p->temporal_enable) c->cur = 1 - c->cur;
     c->gcur = gnew;

@@ -32,7 +32,7 @@ extern "C" {
 #endif
 
 #define SVGF_VERSION_MAJOR 0
-#define SVGF_VERSION_MINOR 7
+#define SVGF_VERSION_MINOR 8
 
 /* ---- error codes (every entry point returns one of these; the library never exits) ---- */
 #define SVGF_OK                 0
@@ -95,10 +95,22 @@ typedef struct SvgfParams {
                                  temporal pass fused into the first level — measured losses) that exist only in
                                  the experiments build of these sources (libsvgf_hip_exp.so, -DSVGF_BUILD_EXPERIMENTS): this
                                  library answers SVGF_ERR_UNSUPPORTED, before anything is enqueued. */
-    int   inputs_ready;       /* accepted and IGNORED since ABI 0.6 (everything is ordered on `stream`).  Rounds 1-3: 1 let the
-                                 temporal pass of this frame run on an internal stream beside the previous frame's trailing
-                                 a-trous levels; it lost 3-8 % once the lane kernel ran every level, and the fused first level
-                                 removes the pass it hid.  The field keeps its place so that the struct layout is unchanged. */
+    int   inputs_ready;       /* ABI 0.8: the FRAME PIPELINE.  Non-zero is a promise about THIS call: (a) the inputs are complete and
+                                 (b) nothing enqueued earlier on `stream` still reads or writes `output`, both at call time and
+                                 until the work of this call is done (alternate two output buffers when frames are enqueued back
+                                 to back).  The library then does not order the frame behind `stream`: it runs even and odd frames
+                                 on two internal streams with two sets of colour planes, starts a frame's temporal pass as soon
+                                 as the level that feeds the previous frame's colour history has run (history_level 1: the
+                                 previous frame's levels 2-5 and this frame's temporal pass + level 1 share the GPU), and makes
+                                 `stream` wait for the frame's end before svgf_denoise returns control of it — so what the caller
+                                 enqueues behind the call sees `output`, exactly as without the promise.  Results are bit-identical
+                                 to ordered frames (tests/test_pipeline_gpu.py); 1080p: 0.260 -> 0.238 ms per frame
+                                 (profiles/r05_exp_pipeline.log).  The first promising frame allocates the second plane set
+                                 (3 x 16 B/px + 3 x 4 B/px) and synchronises the device, once.  0 = everything ordered on
+                                 `stream` (the reference's behaviour; frames of a pipelined context then wait for `stream` first).
+                                 Ignored — the frame is ordered — on the planar path and while `stream` is being captured into a
+                                 graph (the internal streams join the capture).  (ABI 0.6-0.7 ignored the field; rounds 1-3 used
+                                 it for a narrower overlap, the temporal pass alone on a side stream, which lost.) */
     float reproj_scale[2];    /* "next" row f4, paper-faithful reprojection: if > 0, the previous-frame clip
                                  coordinate is divided by it before the ndc mapping: (tan(FOVY) * W / H, tan(FOVY)) =
                                  (pixelLength.x * W / 2, pixelLength.y * H / 2) makes the reprojection exact for any field
@@ -168,6 +180,11 @@ int svgf_sync(svgf_ctx *ctx);
  * the captured call, so replay a graph of TWO consecutive frames (or any even number) to keep the context's rotation consistent
  * (tests/test_stream_gpu.py). */
 int svgf_sync_stream(svgf_ctx *ctx, void *stream);
+
+/* 1 once a frame with SvgfParams::inputs_ready has switched the context to the frame pipeline (second plane set and internal
+ * streams exist; ABI 0.8), else 0.  The promise is only taken up by frames with a temporal pass and a cascade of two or more
+ * levels: a context that never sees one stays as it was. */
+int svgf_is_pipelined(const svgf_ctx *ctx);
 
 /* 0 for this (product) build; 1 for the experiments build of the same sources, which additionally accepts kernel_variant 5 / 6
  * and exports a tuning entry point that is deliberately not declared here. */

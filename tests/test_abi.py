@@ -40,7 +40,7 @@ def test_params_default_matches_reference_ui_defaults(pkg):
     q = pkg.reference_defaults()        # reference src/main.cpp:49-62
     for name, _ in pkg.SvgfParams._fields_[:15]:
         assert getattr(p, name) == pytest.approx(getattr(q, name)), name
-    assert lib.svgf_version() == (0 << 16) | 7
+    assert lib.svgf_version() == (0 << 16) | 8
 
 
 def test_params_size_is_exported_and_checked(pkg):

@@ -1,0 +1,169 @@
+"""The frame pipeline (SvgfParams::inputs_ready, ABI 0.8): consecutive frames of ONE sequence on two internal streams.
+
+A frame's temporal pass needs of the previous frame only what exists once the level that feeds the colour history has run (level 1 with
+the reference's defaults, src/denoise.cu:391); levels 2-5 of frame n and the temporal pass + level 1 of frame n+1 are independent.  A
+caller that promises `inputs_ready` (inputs complete and `out` free at call time) lets the library run even and odd frames on two
+internal streams with two plane sets; the kernels are the same, the data are the same, so every result must be BIT-IDENTICAL to the
+same frames ordered on one stream — for every position of the history level, across mode switches, debug views, non-temporal frames,
+resets, on odd sizes, and under a stream capture (which the pipeline joins instead of escaping).
+(tests/test_parity_gpu.py::test_back_to_back_asynchronous_frames_equal_synchronised_frames covers history levels 0 / 1 / 3 / 5 at
+1920x1080 with the state read-back.)"""
+import ctypes
+import threading
+
+import numpy as np
+import pytest
+from conftest import relerr
+
+pytestmark = pytest.mark.gpu
+
+
+def _inputs(pkg, W, H, n, seed, moving=True):
+    import torch
+    fr = [pkg.synth.render_frame(W, H, f, seed=seed, moving=moving) for f in range(n)]
+    return fr, [torch.from_numpy(f[0]).cuda() for f in fr], [torch.from_numpy(f[1].view(np.uint8).reshape(-1)).cuda() for f in fr]
+
+
+def _run(pkg, W, H, fr, tin, tg, plist, stream=None, reset_at=()):
+    """One context, one frame per entry of plist (SvgfParams), every frame its own output buffer."""
+    import torch
+    d = pkg.Denoiser(W, H, 0)
+    outs = [torch.empty((H, W, 3), dtype=torch.float32, device="cuda") for _ in plist]
+    s = stream or torch.cuda.current_stream()
+    for k, p in enumerate(plist):
+        if k in reset_at:
+            d.reset()
+        d.denoise(outs[k], tin[k % len(tin)], tg[k % len(tg)], fr[k % len(fr)][2], p, stream=s)
+    d.sync()
+    res = [o.cpu().numpy() for o in outs], d.read_state(0), d.read_state(1), d.read_state(2)
+    d.free()
+    return res
+
+
+@pytest.mark.parametrize("size", [(640, 360), (257, 131), (33, 7), (1, 1), (961, 90)])
+def test_pipelined_frames_are_bit_identical_to_ordered_frames(pkg, size):
+    W, H = size
+    fr, tin, tg = _inputs(pkg, W, H, 5, seed=11)
+    base = pkg.reference_defaults().set(temporal_enable=1, spatial_enable=1, atrous_nlevel=5, history_level=1)
+    want = _run(pkg, W, H, fr, tin, tg, [base] * 10)
+    got = _run(pkg, W, H, fr, tin, tg, [pkg.SvgfParams.from_buffer_copy(base).set(inputs_ready=1)] * 10)
+    for k in range(10):
+        assert np.array_equal(want[0][k], got[0][k]), f"{W}x{H} frame {k}"
+    for a, b in zip(want[1:], got[1:]):
+        assert np.array_equal(a, b)
+
+
+def test_mode_switches_debug_views_non_temporal_frames_and_a_reset(pkg):
+    """The promise comes and goes from frame to frame; some frames are debug views (which read the history lengths the next temporal
+    pass rewrites), some have no cascade, some no temporal pass, the history level moves, and the context is reset in the middle."""
+    W, H = 480, 270
+    fr, tin, tg = _inputs(pkg, W, H, 6, seed=5)
+    ref = pkg.reference_defaults()
+    mk = lambda **kw: pkg.SvgfParams.from_buffer_copy(ref).set(**kw)      # noqa: E731
+    seq = [dict(temporal_enable=1, spatial_enable=1, history_level=1), dict(temporal_enable=1, spatial_enable=1, history_level=1),
+           dict(temporal_enable=1, spatial_enable=1, history_level=1, right_view_option=1),      # history-length view
+           dict(temporal_enable=1, spatial_enable=1, history_level=3), dict(temporal_enable=1, spatial_enable=1, history_level=0),
+           dict(temporal_enable=1, spatial_enable=0), dict(temporal_enable=0, spatial_enable=1, atrous_nlevel=2),
+           dict(temporal_enable=1, spatial_enable=1, history_level=5), dict(temporal_enable=1, spatial_enable=1, history_level=1, right_view_option=2),
+           dict(temporal_enable=1, spatial_enable=1, history_level=2, atrous_nlevel=3), dict(temporal_enable=1, spatial_enable=1, history_level=1),
+           dict(temporal_enable=1, spatial_enable=1, history_level=1), dict(temporal_enable=1, spatial_enable=1, history_level=6),
+           dict(temporal_enable=1, spatial_enable=1, history_level=1)]
+    promise = [1, 1, 1, 0, 1, 1, 1, 0, 0, 1, 1, 1, 1, 1]
+    want = _run(pkg, W, H, fr, tin, tg, [mk(**kw) for kw in seq], reset_at=(9,))
+    got = _run(pkg, W, H, fr, tin, tg, [mk(inputs_ready=pr, **kw) for kw, pr in zip(seq, promise)], reset_at=(9,))
+    for k in range(len(seq)):
+        assert np.array_equal(want[0][k], got[0][k]), f"frame {k} ({seq[k]}, promise {promise[k]})"
+    for a, b in zip(want[1:], got[1:]):
+        assert np.array_equal(a, b)
+
+
+def test_pipelined_1080p_sequence_matches_the_oracle(pkg, orc):
+    W, H = 1920, 1080
+    p = pkg.reference_defaults().set(temporal_enable=1, spatial_enable=1, atrous_nlevel=5, history_level=1, inputs_ready=1)
+    fr, tin, tg = _inputs(pkg, W, H, 4, seed=71)
+    got = _run(pkg, W, H, fr, tin, tg, [p] * 4)[0]
+    o = orc.Oracle(pkg, W, H, threads=16)
+    worst = 0.0
+    for k in range(4):
+        ref = o.denoise(fr[k][0], fr[k][1], fr[k][2], p)
+        e = relerr(got[k], ref)
+        assert e.max() <= 1e-4, f"frame {k}: {e.max():.3e}"
+        worst = max(worst, float(e.max()))
+    o.free()
+    print(f"pipelined 1920x1080, 4 moving frames vs oracle: worst max-rel {worst:.2e}")
+
+
+def test_a_pipelined_context_joins_a_stream_capture(pkg):
+    """Under hipStreamBeginCapture nothing can be promised: the frame's internal stream waits for the capturing stream (fork) and
+    the capturing stream waits for the frame's end (join), so the whole frame is part of the graph.  Two frames per graph (plane
+    parities), replayed three times, against the same eight frames run eagerly."""
+    import torch
+    for ln in open("/proc/self/maps"):
+        if "libamdhip64" in ln:
+            hip = ctypes.CDLL(ln.split()[-1])
+            break
+    W, H = 640, 360
+    fr, tin, tg = _inputs(pkg, W, H, 2, seed=9, moving=False)
+    p = pkg.reference_defaults().set(temporal_enable=1, spatial_enable=1, atrous_nlevel=5, history_level=1, inputs_ready=1)
+    want = _run(pkg, W, H, fr, tin, tg, [p] * 8)[0]
+    d = pkg.Denoiser(W, H, 0)
+    s = torch.cuda.Stream()
+    outs = [torch.empty((H, W, 3), dtype=torch.float32, device="cuda") for _ in range(2)]
+    got = []
+    for k in range(2):          # eager: the context becomes pipelined here (allocation + device synchronisation, once)
+        d.denoise(outs[k], tin[k], tg[k], fr[k][2], p, stream=s)
+    s.synchronize()
+    got += [o.cpu().numpy() for o in outs]
+    graph, gexec = ctypes.c_void_p(), ctypes.c_void_p()
+    assert hip.hipStreamBeginCapture(ctypes.c_void_p(s.cuda_stream), 0) == 0
+    for k in range(2):
+        d.denoise(outs[k], tin[k], tg[k], fr[k][2], p, stream=s)
+    assert hip.hipStreamEndCapture(ctypes.c_void_p(s.cuda_stream), ctypes.byref(graph)) == 0
+    assert hip.hipGraphInstantiate(ctypes.byref(gexec), graph, None, None, 0) == 0
+    for rep in range(3):
+        assert hip.hipGraphLaunch(gexec, ctypes.c_void_p(s.cuda_stream)) == 0
+        s.synchronize()
+        got += [o.cpu().numpy() for o in outs]
+    hip.hipGraphExecDestroy(gexec); hip.hipGraphDestroy(graph)
+    d.free()
+    for k in range(8):
+        assert np.array_equal(want[k], got[k]), f"frame {k}"
+
+
+def test_two_pipelined_contexts_from_two_host_threads(pkg):
+    W, H, N = 800, 450, 12
+    fr, tin, tg = _inputs(pkg, W, H, 4, seed=21)
+    p0 = pkg.reference_defaults().set(temporal_enable=1, spatial_enable=1, atrous_nlevel=5, history_level=1)
+    want = _run(pkg, W, H, fr, tin, tg, [p0] * N)[0]
+    res = {}
+
+    def work(tag):
+        import torch
+        p = pkg.SvgfParams.from_buffer_copy(p0).set(inputs_ready=1)
+        res[tag] = _run(pkg, W, H, fr, tin, tg, [p] * N, stream=torch.cuda.Stream())[0]
+    ts = [threading.Thread(target=work, args=(t,)) for t in ("a", "b")]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    for tag in ("a", "b"):
+        for k in range(N):
+            assert np.array_equal(want[k], res[tag][k]), f"thread {tag} frame {k}"
+
+
+def test_profile_entries_of_pipelined_frames(pkg):
+    W, H = 1920, 1080
+    fr, tin, tg = _inputs(pkg, W, H, 2, seed=3, moving=False)
+    import torch
+    p = pkg.reference_defaults().set(temporal_enable=1, spatial_enable=1, atrous_nlevel=5, history_level=1, inputs_ready=1)
+    d = pkg.Denoiser(W, H, 0)
+    d.profile_enable(6)
+    outs = [torch.empty((H, W, 3), dtype=torch.float32, device="cuda") for _ in range(2)]
+    for k in range(6):
+        d.denoise(outs[k & 1], tin[k & 1], tg[k & 1], fr[k & 1][2], p)
+    d.sync()
+    for s in range(6):
+        ent = d.profile_read(s)
+        assert [k for k, _ in ent] == [pkg.binding.KERNEL_TEMPORAL] + [pkg.binding.KERNEL_ATROUS] * 5, ent
+        assert all(0.005 < ms < 1.0 for _, ms in ent), ent
+    d.free()

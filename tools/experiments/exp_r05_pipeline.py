@@ -1,0 +1,101 @@
+#!/usr/bin/env python3
+"""Round 5: the frame pipeline (SvgfParams::inputs_ready) against ordered frames on one stream — bit-identity and throughput.
+usage: exp_r05_pipeline.py [--size 1920x1080] [--frames 400] [--moving]"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import __graft_entry__ as ge      # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--size", default="1920x1080")
+    ap.add_argument("--frames", type=int, default=400)
+    ap.add_argument("--moving", action="store_true")
+    ap.add_argument("--history-level", type=int, default=1)
+    ap.add_argument("--soak", type=int, default=0, help="N frames ordered and N frames pipelined (random parameter changes every 97 frames), last outputs and state compared bit for bit")
+    a = ap.parse_args()
+    W, H = (int(v) for v in a.size.split("x"))
+    import torch
+    pkg = ge.load_package()
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    import telemetry
+    nsrc = 16 if a.moving else 4
+    cams = [pkg.synth.camera_for_frame(f, a.moving) for f in range(nsrc)]
+    di = [torch.empty((H, W, 3), dtype=torch.float32, device="cuda") for _ in range(nsrc)]
+    dg = [torch.empty((H * W * 52,), dtype=torch.uint8, device="cuda") for _ in range(nsrc)]
+    for f in range(nsrc):
+        pkg.binding.synth_render(di[f], dg[f], W, H, cams[f], frame=f, seed=77)
+    torch.cuda.synchronize()
+    stream = torch.cuda.Stream()
+    if a.soak:
+        rng = np.random.default_rng(5)
+        plan = [(int(rng.integers(0, 6)), float(rng.uniform(0.05, 0.3)), int(rng.integers(2, 6))) for _ in range(a.soak // 97 + 1)]
+        fin = {}
+        for mode in ("ordered", "pipelined"):
+            d = pkg.Denoiser(W, H, 0)
+            ob = [torch.empty((H, W, 3), dtype=torch.float32, device="cuda") for _ in range(4)]
+            t0 = time.perf_counter()
+            for f in range(a.soak):
+                hl, alpha, nl = plan[f // 97]
+                p = pkg.reference_defaults().set(temporal_enable=1, spatial_enable=1, atrous_nlevel=nl, history_level=hl, color_alpha=alpha,
+                                                 inputs_ready=1 if mode == "pipelined" else 0)
+                d.denoise(ob[f & 3], di[f % nsrc], dg[f % nsrc], cams[f % nsrc], p, stream=stream)
+                if f % 256 == 255:
+                    stream.synchronize()
+            torch.cuda.synchronize()
+            fin[mode] = ([o.cpu().numpy() for o in ob], d.read_state(0), d.read_state(1), d.read_state(2))
+            print(f"soak {mode}: {a.soak} frames in {time.perf_counter() - t0:.2f} s, pipelined context: {d.is_pipelined()}", flush=True)
+            d.free()
+        ok = all(np.array_equal(x, y) for x, y in zip(fin["ordered"][0], fin["pipelined"][0])) and all(np.array_equal(x, y) for x, y in zip(fin["ordered"][1:], fin["pipelined"][1:]))
+        print(f"soak: last four outputs, history lengths, moments and colour history after {a.soak} frames equal bit for bit: {ok}")
+        return
+    NCHK = 12
+    res = {}
+    for mode in ("ordered", "pipelined"):
+        p = pkg.reference_defaults().set(temporal_enable=1, spatial_enable=1, atrous_nlevel=5, history_level=a.history_level,
+                                         inputs_ready=1 if mode == "pipelined" else 0)
+        d = pkg.Denoiser(W, H, 0)
+        outs = [torch.empty((H, W, 3), dtype=torch.float32, device="cuda") for _ in range(NCHK)]
+        for f in range(NCHK):      # every frame its own output buffer (the pipeline's promise: `out` is free at call time)
+            d.denoise(outs[f], di[f % nsrc], dg[f % nsrc], cams[f % nsrc], p, stream=stream)
+        torch.cuda.synchronize()
+        res[mode] = [o.cpu().numpy() for o in outs]
+        hl = d.read_state(0).copy()
+        res[mode + "_hlen"] = hl
+        # throughput, sustained state; two output buffers in turn
+        ob = [torch.empty((H, W, 3), dtype=torch.float32, device="cuda") for _ in range(2)]
+        for rep in range(3):
+            t0 = time.perf_counter()
+            while time.perf_counter() - t0 < 0.6:
+                for f in range(40):
+                    d.denoise(ob[f & 1], di[f % nsrc], dg[f % nsrc], cams[f % nsrc], p, stream=stream)
+                torch.cuda.synchronize()
+            tm = telemetry.Sampler(period_s=0.002)
+            tm.start()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for f in range(a.frames):
+                d.denoise(ob[f & 1], di[f % nsrc], dg[f % nsrc], cams[f % nsrc], p, stream=stream)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            tm.stop()
+            sm = tm.summary(t0, t1)
+            us = (t1 - t0) / a.frames * 1e6
+            print(f"{mode:9s} {W}x{H} history_level {a.history_level}: {us:.1f} us per frame = {W * H / us:.0f} Mpix/s "
+                  f"(power {(sm.get('power_w') or {}).get('median')} W, sclk {(sm.get('sclk_mhz') or {}).get('median')} MHz)", flush=True)
+        d.free()
+    same = all(np.array_equal(x, y) for x, y in zip(res["ordered"], res["pipelined"]))
+    print("pipelined == ordered on", NCHK, "frames (bit for bit):", same, "| history lengths equal:", np.array_equal(res["ordered_hlen"], res["pipelined_hlen"]))
+    if not same:
+        for f, (x, y) in enumerate(zip(res["ordered"], res["pipelined"])):
+            print("  frame", f, "max abs diff", float(np.abs(x - y).max()))
+
+
+if __name__ == "__main__":
+    main()
