@@ -112,6 +112,10 @@ def test_bench_distributed_branch_runs_with_one_rank_on_rccl():
     vv = line["roofline"]["valu_view"]
     assert vv["simd_instruction_active_pmc"] is None or 0.5 < vv["simd_instruction_active_pmc"] <= 1.01      # a PMC record or nothing: never a literal
     assert "formula" in vv["fp32_tflops_isolated_is"] and "formula" in line["roofline"]["transcendental_gops_isolated_is"]
+    # the frame pipeline is the default of the benchmark; the line carries the ordered figure of the same process beside it, and the
+    # kernels' own durations (ordered frames) beside the durations of the timed region (two frames' kernels sharing the GPU)
+    assert line["frame_pipeline"] is True and line["ordered"]["ms_per_step"] > 0
+    assert line["roofline"]["kernels_in_flight_mean"] > 1.0 and line["roofline"]["isolated"]["frac"] > line["roofline"]["frac"]
 
 
 @pytest.mark.gpu

@@ -12,6 +12,7 @@ if [ "$1" != "quick" ]; then
 timeout 2400 python -m pytest tests -m gpu -q -rA 2>&1 | grep -E "passed|failed|error|worst|PASSED.*(4k|room|1080p)|max rel" | tail -40 > $O/gpu_tests.txt
 fi
 python bench.py --steps 20 --warmup 5 > $O/bench_line_driver_cmd.json 2> $O/bench_driver_cmd.err
+python bench.py --steps 20 --warmup 5 --no-pipeline > $O/bench_line_driver_cmd_no_pipeline.json 2>> $O/bench_driver_cmd.err
 python bench.py --no-cpu-baseline > $O/bench_line.json 2>/dev/null
 python bench.py --no-cpu-baseline --planar-inputs > $O/bench_line_planar_inputs.json 2>/dev/null
 python bench.py --no-cpu-baseline --config 1080p-moving > $O/bench_line_1080p_moving.json 2>/dev/null
@@ -24,10 +25,16 @@ python tools/probe.py --variants 0,4,2 --reps 200 --sustain 0.6 > $O/probe_1080p
 # configs[3] / the "LDS-tile sizing" run: the lane kernel's 480-column x 6-row ring tiles against the strip kernel's 256-column x 2-row tiles
 python tools/probe.py --variants 0,2 --size 3840x2160 --frames 8 --reps 60 --sustain 0.6 > $O/probe_4k.log 2>&1
 examples/farm 8 32 1920 1080 > $O/farm_cpp_8_contexts_1080p.txt 2>&1
+python tools/experiments/exp_r05_pipeline.py > $O/pipeline_vs_ordered_1080p.log 2>&1
+python tools/experiments/exp_r05_pipeline.py --moving --soak 20000 > $O/pipeline_soak.log 2>&1
 cd /tmp && export TMPDIR=/tmp
 # ---- 1080p: kernel trace of the driver's command, SQ pass, HBM passes ----
 rocprofv3 --kernel-trace --stats -d $O/prof -o p --output-format csv -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_line_under_rocprofv3.json 2>/dev/null
 cp $(find $O/prof -name "*kernel_stats.csv" | head -1) $O/rocprofv3_kernel_stats_bench.csv 2>/dev/null
+rm -rf $O/prof
+# the same with every frame ordered on the one stream: one kernel at a time on the GPU, the kernels' own durations
+rocprofv3 --kernel-trace --stats -d $O/prof -o p --output-format csv -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-pipeline > $O/bench_line_no_pipeline_under_rocprofv3.json 2>/dev/null
+cp $(find $O/prof -name "*kernel_stats.csv" | head -1) $O/rocprofv3_kernel_stats_bench_ordered.csv 2>/dev/null
 rm -rf $O/prof
 rocprofv3 -i $R/tools/pmc2.txt -d $O/pmc_sq -o p --output-format csv -- python $R/tools/probe.py --variants 0 --frames 6 > /dev/null 2>&1
 python $R/tools/pmc_summary.py $O/pmc_sq "atrous" > $O/pmc_sq.txt
@@ -40,6 +47,9 @@ rm -rf $O/pmc_hbm
 # ---- 3840x2160 (configs[3]): the same three ----
 rocprofv3 --kernel-trace --stats -d $O/prof4k -o p --output-format csv -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --config 4k-static > $O/bench_line_4k_under_rocprofv3.json 2>/dev/null
 cp $(find $O/prof4k -name "*kernel_stats.csv" | head -1) $O/rocprofv3_kernel_stats_4k.csv 2>/dev/null
+rm -rf $O/prof4k
+rocprofv3 --kernel-trace --stats -d $O/prof4k -o p --output-format csv -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-pipeline --config 4k-static > $O/bench_line_4k_no_pipeline_under_rocprofv3.json 2>/dev/null
+cp $(find $O/prof4k -name "*kernel_stats.csv" | head -1) $O/rocprofv3_kernel_stats_4k_ordered.csv 2>/dev/null
 rm -rf $O/prof4k
 rocprofv3 -i $R/tools/pmc2.txt -d $O/pmc_sq4k -o p --output-format csv -- python $R/tools/probe.py --variants 0 --size 3840x2160 --frames 6 --reps 10 > /dev/null 2>&1
 python $R/tools/pmc_summary.py $O/pmc_sq4k "atrous" > $O/pmc_sq_4k.txt
