@@ -529,7 +529,7 @@ def main():
                          "mean_launch_us": round(a_ms * 1e3, 2), "launches_timed": len(atrous_ms),
                          # with the frame pipeline the kernels of two consecutive frames share the GPU: a launch of the timed region
                          # lasts longer than the same launch alone ('isolated' below: ordered frames), while more than one is in flight
-                         "kernels_in_flight_mean": round((sum(atrous_ms) + sum(temporal_ms) + sum(fused_ms)) / max(1, len(temporal_ms) + len(fused_ms)) / (dt / a.steps * 1e3), 3)
+                         "kernels_in_flight_mean": round(((0.0 if level_is_fused else sum(atrous_ms)) + sum(temporal_ms) + sum(fused_ms)) / max(1, len(temporal_ms) + len(fused_ms)) / (dt / a.steps * 1e3), 3)
                                                    if (temporal_ms or fused_ms) else None,
                          "launch_includes_fused_prepare_pass": level_is_fused,
                          "note": ("frame pipeline on: the kernels of consecutive frames overlap, 'achieved' / 'frac' are the launches of the timed region as they ran (sharing the GPU); " if pipeline else "everything ordered on one stream; ")
