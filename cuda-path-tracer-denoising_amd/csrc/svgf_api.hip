@@ -602,8 +602,9 @@ static int denoise_frame(svgf_ctx *c, void *out_rgb_dev, const void *in_rgb_dev,
     // (The promise is a permission: it is used where there is something to overlap — a temporal pass and a cascade of two or more
     // levels.  A one-launch frame like BASELINE configs[0] loses more to the four cross-stream events of a pipelined frame than it
     // can gain: 0.0247 -> 0.0342 ms measured, profiles/r05_exp_pipeline.log.)
+    // Nor where nothing CAN overlap: with the colour history taken from the LAST level the next temporal pass needs the whole frame.
     bool promise = (p->inputs_ready != 0) && gbuffer_dev != nullptr && p->temporal_enable && p->spatial_enable && p->atrous_nlevel >= 2 &&
-                   p->right_view_option != 1 && p->right_view_option != 2;
+                   p->right_view_option != 1 && p->right_view_option != 2 && p->history_level != p->atrous_nlevel;
     unsigned long long cap_id = 0;      // != 0: `stream` is being captured into a graph
     if (promise || c->pipelined) {
         hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
@@ -709,6 +710,12 @@ static int denoise_frame(svgf_ctx *c, void *out_rgb_dev, const void *in_rgb_dev,
     c->vp_valid &= ~(1u << acc);     // the temporal / prepare pass writes no variance plane: the first level gathers cv.w
     c->acc = acc;
     c->hist = acc;                                   // color_history <- color_acc / input (:366,370)
+    if (piped && cascade && p->temporal_enable && !(p->history_level >= 1 && p->history_level <= p->atrous_nlevel)) {
+        // no level of this cascade writes the colour history: it IS the accumulated plane (which no level of this frame overwrites),
+        // and everything else the next temporal pass reads was final before: the other stream may go on behind the temporal pass
+        HIPC(c, hipEventRecord(c->ev_hist[pq], s));
+        c->ev_hist_valid[pq] = 1; c->ev_hist_cap[pq] = cap_id; hist_event_recorded = true;
+    }
     if (c->capture && !fused) { HIPC(c, hipMemcpyAsync(c->cv_capture, c->cv[acc], c->n * sizeof(float4), hipMemcpyDeviceToDevice, s)); }
 
     // 2) debug views, pass-through or the a-trous cascade (:373-394)
