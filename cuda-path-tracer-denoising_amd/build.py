@@ -73,14 +73,16 @@ def build_hip(force: bool = False, experiments: bool = False) -> str:
 
 
 def build_examples(force: bool = False) -> str:
-    """examples/farm.cpp (N contexts on N GPUs from one C++ process, through the C ABI) -> examples/farm, linked against the product
-    library in-tree."""
-    src = os.path.join(ROOT, "examples", "farm.cpp")
-    out = os.path.join(ROOT, "examples", "farm")
-    if not force and _newer(out, [src, os.path.join(ROOT, "include", "svgf.h"), LIB]):
-        return out
-    tmp = out + f".tmp{os.getpid()}"
-    _run([hipcc_path(), "--offload-arch=gfx950", "-O2", "-I", os.path.join(ROOT, "include"), src, "-L", _HERE, "-lsvgf_hip",
-          "-Wl,-rpath," + _HERE, "-Wl,-rpath,$ORIGIN/../cuda-path-tracer-denoising_amd", "-o", tmp])
-    os.replace(tmp, out)
+    """examples/farm.cpp (N contexts on N GPUs from one C++ process) and examples/pipeline.cpp (a renderer's frame loop on the frame
+    pipeline), through the C ABI -> examples/farm, examples/pipeline, linked against the product library in-tree."""
+    out = ""
+    for name in ("pipeline", "farm"):
+        src = os.path.join(ROOT, "examples", name + ".cpp")
+        out = os.path.join(ROOT, "examples", name)
+        if not force and _newer(out, [src, os.path.join(ROOT, "include", "svgf.h"), LIB]):
+            continue
+        tmp = out + f".tmp{os.getpid()}"
+        _run([hipcc_path(), "--offload-arch=gfx950", "-O2", "-I", os.path.join(ROOT, "include"), src, "-L", _HERE, "-lsvgf_hip",
+              "-Wl,-rpath," + _HERE, "-Wl,-rpath,$ORIGIN/../cuda-path-tracer-denoising_amd", "-o", tmp])
+        os.replace(tmp, out)
     return out

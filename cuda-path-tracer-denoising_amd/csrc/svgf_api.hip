@@ -48,6 +48,8 @@ struct svgf_ctx {
     hipEvent_t ev_hist[2], ev_done[2], ev_in;
     int ev_hist_valid[2];
     unsigned long long ev_hist_cap[2];      // the stream-capture id ev_hist[q] was last recorded under (0: eagerly)
+    int ev_done_valid[2];
+    unsigned long long ev_done_cap[2];
     long long pipe_frames;     // frames since the context became pipelined (parity = stream and plane set)
     int use_vplane;        // 0 only for A/B measurements (experiments build: svgf_exp_set("no_variance_plane", 1) before svgf_create)
     void *dump;            // 4 KB of scrap for the fused kernel (TemporalArgs::dump)
@@ -232,6 +234,7 @@ static int zero_state(svgf_ctx *c)
     for (int k = 0; k < 6; k++) if (c->vp[k]) HIPC(c, hipMemset(c->vp[k], 0, (size_t)(c->W + 2) * (c->H + 2) * sizeof(float) + 64));
     c->vp_valid = 0;
     c->pipe_frames = 0; c->ev_hist_valid[0] = c->ev_hist_valid[1] = 0; c->ev_hist_cap[0] = c->ev_hist_cap[1] = 0;      // (a pipelined context stays pipelined)
+    c->ev_done_valid[0] = c->ev_done_valid[1] = 0; c->ev_done_cap[0] = c->ev_done_cap[1] = 0;
     for (int k = 0; k < 2; k++) {
         HIPC(c, hipMemset(c->nrm[k], 0, c->n * 3 * sizeof(float)));
         HIPC(c, hipMemset(c->gid[k], 0, c->n * sizeof(int)));
@@ -515,6 +518,7 @@ static int ensure_pipeline(svgf_ctx *c)
     HIPC(c, hipDeviceSynchronize());
     c->pipelined = 1;
     c->pipe_frames = 0; c->ev_hist_valid[0] = c->ev_hist_valid[1] = 0;
+    c->ev_done_valid[0] = c->ev_done_valid[1] = 0;
     return SVGF_OK;
 }
 
@@ -594,19 +598,25 @@ static int denoise_frame(svgf_ctx *c, void *out_rgb_dev, const void *in_rgb_dev,
     SvgfDeviceGuard dev_guard(c->device);
     if (!dev_guard.ok) { snprintf(c->err, sizeof(c->err), "hipSetDevice(%d) failed", c->device); return SVGF_ERR_HIP; }
     hipStream_t s_user = (hipStream_t)stream;
-    // Pipelined frames (see svgf_ctx::pipelined).  The promise behind inputs_ready: at call time the inputs are complete, nothing
+    // Pipelined frames (see svgf_ctx::pipelined).  The promise behind inputs_ready = 1: at call time the inputs are complete, nothing
     // enqueued earlier on `stream` still reads `out`, and both stay untouched until the work of this call is done — so the frame need
-    // not order itself behind the caller's stream (which has waited for the PREVIOUS frame's end).  Without the promise a frame of a
-    // pipelined context waits for the caller's stream position first; under stream capture nothing is promised (the internal stream
-    // joins the capture through that wait).  The planar path and the experiments build's fused temporal pass stay ordered.
+    // not order itself behind the caller's stream (which has waited for the PREVIOUS frame's end) and runs on an internal stream.
+    // Without the promise a frame of a pipelined context runs on the caller's stream, like any frame of any context, behind the last
+    // frame that used its plane set and the history of the frame before it; under stream capture nothing is promised (the frame is
+    // recorded on the capturing stream).  The planar path and the experiments build's fused temporal pass never pipeline.
     // (The promise is a permission: it is used where there is something to overlap — a temporal pass and a cascade of two or more
     // levels.  A one-launch frame like BASELINE configs[0] loses more to the four cross-stream events of a pipelined frame than it
     // can gain: 0.0247 -> 0.0342 ms measured, profiles/r05_exp_pipeline.log.)
     // Nor where nothing CAN overlap: with the colour history taken from the LAST level the next temporal pass needs the whole frame.
-    bool promise = (p->inputs_ready != 0) && gbuffer_dev != nullptr && p->temporal_enable && p->spatial_enable && p->atrous_nlevel >= 2 &&
-                   p->right_view_option != 1 && p->right_view_option != 2 && p->history_level != p->atrous_nlevel;
+    // inputs_ready == 2 asks for the pipeline WITHOUT the promise: the frame is ordered behind `stream` like any other work (its
+    // inputs may be produced there, its output consumed there), and a caller that alternates TWO streams from frame to frame gets
+    // the same overlap with nothing but stream semantics — a stream only ever waits for the frames that were given to it.
+    const bool worth = gbuffer_dev != nullptr && p->temporal_enable && p->spatial_enable && p->atrous_nlevel >= 2 &&
+                       p->right_view_option != 1 && p->right_view_option != 2 && p->history_level != p->atrous_nlevel;
+    bool promise = (p->inputs_ready == 1) && worth;
+    bool want_pipeline = (p->inputs_ready != 0) && worth;
     unsigned long long cap_id = 0;      // != 0: `stream` is being captured into a graph
-    if (promise || c->pipelined) {
+    if (want_pipeline || c->pipelined) {
         hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
         unsigned long long id = 0;
         if (s_user && hipStreamGetCaptureInfo(s_user, &cs, &id) == hipSuccess && cs != hipStreamCaptureStatusNone) { cap_id = id ? id : 1; promise = false; }
@@ -615,16 +625,22 @@ static int denoise_frame(svgf_ctx *c, void *out_rgb_dev, const void *in_rgb_dev,
         if (!cap_id && (c->ev_hist_cap[0] || c->ev_hist_cap[1])) promise = false;
     }
 #ifdef SVGF_BUILD_EXPERIMENTS
-    if (p->kernel_variant == 6 || p->kernel_variant == 5 || c->use_reuse || c->use_split_fused) promise = false;
+    if (p->kernel_variant == 6 || p->kernel_variant == 5 || c->use_reuse || c->use_split_fused) { promise = false; want_pipeline = false; }
 #endif
-    if (promise && !c->pipelined) { const int rc = ensure_pipeline(c); if (rc != SVGF_OK) return rc; }
+    if (want_pipeline && !cap_id && !c->pipelined) { const int rc = ensure_pipeline(c); if (rc != SVGF_OK) return rc; }
     const bool piped = c->pipelined != 0;
     const int pq = piped ? (int)(c->pipe_frames & 1) : 0;
     const int pbase = piped ? 3 * pq : 0;          // this frame's plane set
-    hipStream_t s = piped ? c->pipe[pq] : s_user;
-    if (piped && (!promise || c->pipe_frames == 0)) {      // ordered behind what the caller's stream holds (always: the first pipelined frame)
-        HIPC(c, hipEventRecord(c->ev_in, s_user));
-        HIPC(c, hipStreamWaitEvent(s, c->ev_in, 0));
+    // A promised frame runs on the context's stream of its parity.  Every other frame of a pipelined context runs on the caller's own
+    // stream, behind the previous frame of the same parity (same plane set), wherever that one ran: with one stream that is what an
+    // ordered frame always was; with two streams used in turn (inputs_ready = 2) the caller's streams ARE the pipeline.
+    hipStream_t s = (piped && promise) ? c->pipe[pq] : s_user;
+    if (piped) {
+        if (promise && c->pipe_frames == 0) {      // the first pipelined frame: behind what the caller's stream holds
+            HIPC(c, hipEventRecord(c->ev_in, s_user));
+            HIPC(c, hipStreamWaitEvent(s, c->ev_in, 0));
+        }
+        if (c->ev_done_valid[pq] && c->ev_done_cap[pq] == cap_id) HIPC(c, hipStreamWaitEvent(s, c->ev_done[pq], 0));
     }
     float *out = (float *)out_rgb_dev;
     const float *in = (const float *)in_rgb_dev;
@@ -842,7 +858,8 @@ static int denoise_frame(svgf_ctx *c, void *out_rgb_dev, const void *in_rgb_dev,
         // the last level — release the next frame at their end: they read state the next temporal pass rewrites)
         if (!hist_event_recorded) { HIPC(c, hipEventRecord(c->ev_hist[pq], s)); c->ev_hist_valid[pq] = 1; c->ev_hist_cap[pq] = cap_id; }
         HIPC(c, hipEventRecord(c->ev_done[pq], s));
-        HIPC(c, hipStreamWaitEvent(s_user, c->ev_done[pq], 0));      // what the caller enqueues behind this call sees `out`
+        c->ev_done_valid[pq] = 1; c->ev_done_cap[pq] = cap_id;
+        if (s != s_user) HIPC(c, hipStreamWaitEvent(s_user, c->ev_done[pq], 0));      // what the caller enqueues behind this call sees `out`
         c->pipe_frames++;
     }
     // 3) history rotation (:396-399): planes swap roles instead of being copied

@@ -107,9 +107,14 @@ typedef struct SvgfParams {
                                  to ordered frames (tests/test_pipeline_gpu.py); 1080p: 0.260 -> 0.238 ms per frame
                                  (profiles/r05_exp_pipeline.log).  The first promising frame allocates the second plane set
                                  (3 x 16 B/px + 3 x 4 B/px) and synchronises the device, once.  0 = everything ordered on
-                                 `stream` (the reference's behaviour; frames of a pipelined context then wait for `stream` first).
-                                 Ignored — the frame is ordered — on the planar path and while `stream` is being captured into a
-                                 graph (the internal streams join the capture).  (ABI 0.6-0.7 ignored the field; rounds 1-3 used
+                                 `stream` (the reference's behaviour; such frames of a pipelined context run on `stream` itself).
+                                 2 = the pipeline WITHOUT the promise: the frame is ordered behind `stream` like any other work
+                                 (inputs produced there, output consumed there), and a caller that alternates TWO streams from
+                                 frame to frame — each with its own input / output buffers — gets the same overlap from plain
+                                 stream semantics, because a stream only waits for the frames that were given to it
+                                 (examples/pipeline.cpp: producer + denoiser of consecutive frames overlapping, no events).
+                                 Ignored — the frame is ordered on `stream` — on the planar path and while `stream` is being
+                                 captured into a graph.  (ABI 0.6-0.7 ignored the field; rounds 1-3 used
                                  it for a narrower overlap, the temporal pass alone on a side stream, which lost.) */
     float reproj_scale[2];    /* "next" row f4, paper-faithful reprojection: if > 0, the previous-frame clip
                                  coordinate is divided by it before the ndc mapping: (tan(FOVY) * W / H, tan(FOVY)) =

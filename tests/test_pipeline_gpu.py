@@ -167,3 +167,49 @@ def test_profile_entries_of_pipelined_frames(pkg):
         assert [k for k, _ in ent] == [pkg.binding.KERNEL_TEMPORAL] + [pkg.binding.KERNEL_ATROUS] * 5, ent
         assert all(0.005 < ms < 1.0 for _, ms in ent), ent
     d.free()
+
+
+def test_cpp_pipeline_example_is_bit_identical_to_frames_in_turn(pkg):
+    """examples/pipeline.cpp: a renderer's frame loop in C++ through the C ABI — the producer of frame n+1 on its own stream beside
+    frame n's denoising, the inputs_ready promise kept by double buffering and events — against the reference's order (render,
+    denoise, render, denoise on one stream).  The program itself compares the last two outputs bit for bit."""
+    import os
+    import subprocess
+    from conftest import ROOT
+    exe = os.path.join(ROOT, "examples", "pipeline")
+    assert os.path.exists(exe), "examples/pipeline is built by __graft_entry__.build()"
+    for args in (["24", "640", "360"], ["9", "257", "131"]):
+        r = subprocess.run([exe] + args, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+        assert r.returncode == 0 and "bit-identical: yes" in r.stdout and "[context pipelined]" in r.stdout, r.stdout
+
+
+def test_two_alternating_streams_without_the_promise(pkg):
+    """inputs_ready = 2: the pipeline, every frame ordered behind the stream it was given to.  Even frames on one stream, odd frames on
+    another, the inputs of each frame COPIED into its buffers on that stream right before the call (so they are not complete at call
+    time) and the output read back by a copy enqueued behind the call on the same stream: bit-identical to ordered frames."""
+    import torch
+    W, H, N = 640, 360, 10
+    fr, tin, tg = _inputs(pkg, W, H, 5, seed=31)
+    p0 = pkg.reference_defaults().set(temporal_enable=1, spatial_enable=1, atrous_nlevel=5, history_level=1)
+    want = _run(pkg, W, H, fr, tin, tg, [p0] * N)[0]
+    p = pkg.SvgfParams.from_buffer_copy(p0).set(inputs_ready=2)
+    d = pkg.Denoiser(W, H, 0)
+    st = [torch.cuda.Stream(), torch.cuda.Stream()]
+    cin = [torch.empty_like(tin[0]) for _ in range(2)]
+    cg = [torch.empty_like(tg[0]) for _ in range(2)]
+    out = [torch.empty((H, W, 3), dtype=torch.float32, device="cuda") for _ in range(2)]
+    keep = [torch.empty((H, W, 3), dtype=torch.float32, device="cuda") for _ in range(N)]
+    torch.cuda.synchronize()
+    for k in range(N):
+        q = k & 1
+        with torch.cuda.stream(st[q]):
+            cin[q].copy_(tin[k % 5], non_blocking=True)
+            cg[q].copy_(tg[k % 5], non_blocking=True)
+            d.denoise(out[q], cin[q], cg[q], fr[k % 5][2], p, stream=st[q])
+            keep[k].copy_(out[q], non_blocking=True)
+    torch.cuda.synchronize()
+    assert d.is_pipelined()
+    got = [o.cpu().numpy() for o in keep]
+    d.free()
+    for k in range(N):
+        assert np.array_equal(want[k], got[k]), f"frame {k}"

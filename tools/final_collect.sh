@@ -8,7 +8,7 @@ for f in gpu_tests.txt bench_line_driver_cmd.json bench_line.json bench_line_pla
          farm_cpp_8_contexts_1080p.txt rocprofv3_kernel_stats_bench.csv rocprofv3_kernel_stats_4k.csv rocprofv3_kernel_stats_bench_planar.csv \
          pmc_sq.txt pmc_hbm.txt pmc_sq_4k.txt pmc_hbm_4k.txt segment_length_4k.log gpu_box.txt bench_line_under_rocprofv3.json bench_line_4k_under_rocprofv3.json \
          bench_line_driver_cmd_no_pipeline.json rocprofv3_kernel_stats_bench_ordered.csv rocprofv3_kernel_stats_4k_ordered.csv \
-         bench_line_no_pipeline_under_rocprofv3.json bench_line_4k_no_pipeline_under_rocprofv3.json pipeline_vs_ordered_1080p.log pipeline_soak.log; do
+         bench_line_no_pipeline_under_rocprofv3.json bench_line_4k_no_pipeline_under_rocprofv3.json pipeline_vs_ordered_1080p.log pipeline_soak.log pipeline_cpp_two_streams.txt; do
   [ -s $O/$f ] && cp $O/$f $P/r05_$f
 done
 sclk() { python - "$1" <<'PY'

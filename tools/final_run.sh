@@ -25,6 +25,7 @@ python tools/probe.py --variants 0,4,2 --reps 200 --sustain 0.6 > $O/probe_1080p
 # configs[3] / the "LDS-tile sizing" run: the lane kernel's 480-column x 6-row ring tiles against the strip kernel's 256-column x 2-row tiles
 python tools/probe.py --variants 0,2 --size 3840x2160 --frames 8 --reps 60 --sustain 0.6 > $O/probe_4k.log 2>&1
 examples/farm 8 32 1920 1080 > $O/farm_cpp_8_contexts_1080p.txt 2>&1
+(examples/pipeline 400 1920 1080; examples/pipeline 600 1280 720; examples/pipeline 200 3840 2160) > $O/pipeline_cpp_two_streams.txt 2>&1
 python tools/experiments/exp_r05_pipeline.py > $O/pipeline_vs_ordered_1080p.log 2>&1
 python tools/experiments/exp_r05_pipeline.py --moving --soak 20000 > $O/pipeline_soak.log 2>&1
 cd /tmp && export TMPDIR=/tmp
