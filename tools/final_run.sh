@@ -9,7 +9,7 @@ O=$R/gpurun_out/final_r05
 mkdir -p $O
 cd $R
 if [ "$1" != "quick" ]; then
-timeout 2400 python -m pytest tests -m gpu -q -rA 2>&1 | grep -E "passed|failed|error|worst|PASSED.*(4k|room|1080p)|max rel" | tail -40 > $O/gpu_tests.txt
+timeout 2400 python -m pytest tests -m gpu -q -rA 2>&1 | grep -E "passed|failed|error|worst|pipelined|PASSED.*(4k|room|1080p)|max rel" | tail -40 > $O/gpu_tests.txt
 fi
 python bench.py --steps 20 --warmup 5 > $O/bench_line_driver_cmd.json 2> $O/bench_driver_cmd.err
 python bench.py --steps 20 --warmup 5 --no-pipeline > $O/bench_line_driver_cmd_no_pipeline.json 2>> $O/bench_driver_cmd.err
