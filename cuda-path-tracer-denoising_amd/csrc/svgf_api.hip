@@ -658,8 +658,8 @@ static int denoise_frame(svgf_ctx *c, void *out_rgb_dev, const void *in_rgb_dev,
     //    colour history, and the current-frame G-buffer planes.  When the frame runs the a-trous cascade on the fast path the
     //    temporal pass is not launched at all: the first level's loader waves accumulate the pixels they stage (fused
     //    kernel, svgf_atrous_fused.hip) and `acc` stays unwritten unless something other than that level needs it.
-    //    (SvgfParams::inputs_ready, the cross-frame overlap of rounds 1-3, is accepted and ignored: it lost 3-8 % once the
-    //    lane kernel ran all five levels, and the fusion removes the pass it used to hide.)
+    //    (Rounds 1-3 ran this pass alone on a side stream beside the previous frame's trailing levels — it lost 3-8 % once the lane
+    //    kernel ran all five levels; round 5's frame pipeline, above, runs whole frames of alternating parity on two streams.)
     const int old_hist = c->hist;
     const int acc = piped ? (pbase == old_hist ? pbase + 1 : pbase) : (old_hist + 1) % 3;
     // the other stream's frame: this frame's temporal pass (and everything behind it) starts when that frame's colour history,
@@ -854,8 +854,8 @@ static int denoise_frame(svgf_ctx *c, void *out_rgb_dev, const void *in_rgb_dev,
     }
 
     if (piped) {
-        // (frames whose history is not the output of a level of the cascade — debug views, pass-through, history_level 0 or beyond
-        // the last level — release the next frame at their end: they read state the next temporal pass rewrites)
+        // (frames without a cascade — debug views, pass-through, non-temporal frames — release the next frame at their end: they read
+        // state the next temporal pass rewrites)
         if (!hist_event_recorded) { HIPC(c, hipEventRecord(c->ev_hist[pq], s)); c->ev_hist_valid[pq] = 1; c->ev_hist_cap[pq] = cap_id; }
         HIPC(c, hipEventRecord(c->ev_done[pq], s));
         c->ev_done_valid[pq] = 1; c->ev_done_cap[pq] = cap_id;
@@ -895,6 +895,11 @@ extern "C" int svgf_planar_gbuffer(svgf_ctx *c, SvgfPlanarGBuffer *out)
         HIPC(c, hipMemset(c->albedo, 0, c->n * 3 * sizeof(float)));
         HIPC(c, hipStreamSynchronize(nullptr));
     }
+    // The planes handed out were the current planes of the frame before last; the producer writes them on a stream of its own
+    // choosing.  On an ordered context that stream has waited for every frame (stream order); frames of a PIPELINED context may still be
+    // running on another stream of the caller's or on the context's own, so the hand-out waits for them — the planar path orders its
+    // frames anyway (svgf_denoise_planar never pipelines).
+    if (c->pipelined) HIPC(c, hipDeviceSynchronize());
     const int gnew = 1 - c->gcur;        // the planes the next frame's temporal / prepare pass treats as "current"
     out->normal = c->nrm[gnew]; out->position = c->pos[gnew]; out->geom_id = c->gid[gnew]; out->albedo = c->albedo;
     return SVGF_OK;
