@@ -598,9 +598,10 @@ static int denoise_frame(svgf_ctx *c, void *out_rgb_dev, const void *in_rgb_dev,
     SvgfDeviceGuard dev_guard(c->device);
     if (!dev_guard.ok) { snprintf(c->err, sizeof(c->err), "hipSetDevice(%d) failed", c->device); return SVGF_ERR_HIP; }
     hipStream_t s_user = (hipStream_t)stream;
-    // Pipelined frames (see svgf_ctx::pipelined).  The promise behind inputs_ready = 1: at call time the inputs are complete, nothing
-    // enqueued earlier on `stream` still reads `out`, and both stay untouched until the work of this call is done — so the frame need
-    // not order itself behind the caller's stream (which has waited for the PREVIOUS frame's end) and runs on an internal stream.
+    // Pipelined frames (see svgf_ctx::pipelined).  The promise behind inputs_ready = 1: at call time the inputs are complete (and stay
+    // untouched until the work of this call is done) — so the frame need not order itself behind the caller's stream, which has
+    // waited for the PREVIOUS frame's end, and runs on an internal stream; only the kernel that writes `out` waits for the caller's
+    // stream position (readers of that buffer enqueued behind earlier calls).
     // Without the promise a frame of a pipelined context runs on the caller's stream, like any frame of any context, behind the last
     // frame that used its plane set and the history of the frame before it; under stream capture nothing is promised (the frame is
     // recorded on the capturing stream).  The planar path and the experiments build's fused temporal pass never pipeline.
@@ -636,9 +637,9 @@ static int denoise_frame(svgf_ctx *c, void *out_rgb_dev, const void *in_rgb_dev,
     // ordered frame always was; with two streams used in turn (inputs_ready = 2) the caller's streams ARE the pipeline.
     hipStream_t s = (piped && promise) ? c->pipe[pq] : s_user;
     if (piped) {
-        if (promise && c->pipe_frames == 0) {      // the first pipelined frame: behind what the caller's stream holds
-            HIPC(c, hipEventRecord(c->ev_in, s_user));
-            HIPC(c, hipStreamWaitEvent(s, c->ev_in, 0));
+        if (promise) {
+            HIPC(c, hipEventRecord(c->ev_in, s_user));      // the caller's stream position at hand-over: the last level waits for it (`out`)
+            if (c->pipe_frames == 0) HIPC(c, hipStreamWaitEvent(s, c->ev_in, 0));      // the first pipelined frame: all of it behind the caller's stream
         }
         if (c->ev_done_valid[pq] && c->ev_done_cap[pq] == cap_id) HIPC(c, hipStreamWaitEvent(s, c->ev_done[pq], 0));
     }
@@ -817,6 +818,10 @@ static int denoise_frame(svgf_ctx *c, void *out_rgb_dev, const void *in_rgb_dev,
                 snprintf(c->err, sizeof(c->err), "svgf_denoise: internal error, the G-buffer split was left to a first level that does not run the lane kernel");
                 return SVGF_ERR_HIP;
             }
+            // The one kernel of a promised frame that writes the caller's `out`: behind what the caller's stream held when the frame
+            // was handed over (a reader of the same buffer enqueued behind an earlier call, for instance).  The promise is about the
+            // INPUTS only; the output buffer is protected by stream order like everywhere else.
+            if (piped && promise && last) HIPC(c, hipStreamWaitEvent(s, c->ev_in, 0));
             switch (which) {
             case K_FUSED:
                 // the accumulated plane itself is only written when something besides this level reads it: a later frame (the

@@ -95,14 +95,14 @@ typedef struct SvgfParams {
                                  temporal pass fused into the first level — measured losses) that exist only in
                                  the experiments build of these sources (libsvgf_hip_exp.so, -DSVGF_BUILD_EXPERIMENTS): this
                                  library answers SVGF_ERR_UNSUPPORTED, before anything is enqueued. */
-    int   inputs_ready;       /* ABI 0.8: the FRAME PIPELINE.  Non-zero is a promise about THIS call: (a) the inputs are complete and
-                                 (b) nothing enqueued earlier on `stream` still reads or writes `output`, both at call time and
-                                 until the work of this call is done (alternate two output buffers when frames are enqueued back
-                                 to back).  The library then does not order the frame behind `stream`: it runs even and odd frames
-                                 on two internal streams with two sets of colour planes, starts a frame's temporal pass as soon
-                                 as the level that feeds the previous frame's colour history has run (history_level 1: the
-                                 previous frame's levels 2-5 and this frame's temporal pass + level 1 share the GPU), and makes
-                                 `stream` wait for the frame's end before svgf_denoise returns control of it — so what the caller
+    int   inputs_ready;       /* ABI 0.8: the FRAME PIPELINE.  1 is a promise about THIS call: the inputs (colour, G-buffer) are
+                                 COMPLETE at call time — not merely enqueued on `stream` — and stay untouched until the work of
+                                 this call is done.  The library then does not order the frame behind `stream`: it runs even and
+                                 odd frames on two internal streams with two sets of colour planes, starts a frame's temporal pass
+                                 as soon as the level that feeds the previous frame's colour history has run (history_level 1: the
+                                 previous frame's levels 2-5 and this frame's temporal pass + level 1 share the GPU), lets only
+                                 the kernel that writes `output` wait for what `stream` held at call time (readers of the same
+                                 buffer behind earlier calls), and makes `stream` wait for the frame's end — so what the caller
                                  enqueues behind the call sees `output`, exactly as without the promise.  Results are bit-identical
                                  to ordered frames (tests/test_pipeline_gpu.py); 1080p: 0.260 -> 0.238 ms per frame
                                  (profiles/r05_exp_pipeline.log).  The first promising frame allocates the second plane set

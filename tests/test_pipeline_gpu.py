@@ -213,3 +213,33 @@ def test_two_alternating_streams_without_the_promise(pkg):
     d.free()
     for k in range(N):
         assert np.array_equal(want[k], got[k]), f"frame {k}"
+
+
+def test_readers_of_the_output_enqueued_behind_earlier_calls_are_safe(pkg):
+    """The promise is about the inputs.  ONE output buffer for every frame, and behind every call a copy of it enqueued on the caller's
+    stream (never waited for by the host): the kernel of frame n+1 that writes the buffer must wait for that copy — it does, through
+    the caller's stream position recorded at hand-over — or the copies would hold torn frames.  (The first version of the promise
+    covered the output buffer as well; a soak loop that reused four buffers with enqueued readers broke it on 8 % of its frames.)"""
+    import torch
+    W, H, N = 640, 360, 40
+    fr, tin, tg = _inputs(pkg, W, H, 5, seed=13)
+    p0 = pkg.reference_defaults().set(temporal_enable=1, spatial_enable=1, atrous_nlevel=5, history_level=1)
+    want = _run(pkg, W, H, fr, tin, tg, [p0] * N)[0]
+    p = pkg.SvgfParams.from_buffer_copy(p0).set(inputs_ready=1)
+    d = pkg.Denoiser(W, H, 0)
+    s = torch.cuda.Stream()
+    out = torch.empty((H, W, 3), dtype=torch.float32, device="cuda")
+    keep = [torch.empty((H, W, 3), dtype=torch.float32, device="cuda") for _ in range(N)]
+    torch.cuda.synchronize()
+    with torch.cuda.stream(s):
+        for k in range(N):
+            d.denoise(out, tin[k % 5], tg[k % 5], fr[k % 5][2], p, stream=s)
+            keep[k].copy_(out, non_blocking=True)
+            for _ in range(3):          # keep the caller's stream busy for a while behind the copy
+                keep[k].mul_(1.0)
+    torch.cuda.synchronize()
+    assert d.is_pipelined()
+    got = [o.cpu().numpy() for o in keep]
+    d.free()
+    for k in range(N):
+        assert np.array_equal(want[k], got[k]), f"frame {k}"

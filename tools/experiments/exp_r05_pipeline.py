@@ -37,23 +37,41 @@ def main():
         rng = np.random.default_rng(5)
         plan = [(int(rng.integers(0, 6)), float(rng.uniform(0.05, 0.3)), int(rng.integers(2, 6))) for _ in range(a.soak // 97 + 1)]
         fin = {}
-        for mode in ("ordered", "pipelined"):
+        for mode in ("ordered", "ordered2", "pipelined", "pipelined2"):
             d = pkg.Denoiser(W, H, 0)
             ob = [torch.empty((H, W, 3), dtype=torch.float32, device="cuda") for _ in range(4)]
+            # EVERY frame's output is reduced to two numbers (sum and sum of squares in float64, enqueued on the caller's stream behind
+            # the call, where the stream has waited for the frame): a transient race would fade from the final state within a few
+            # hundred frames of temporal accumulation, but not from this record
+            chk = torch.zeros((a.soak, 2), dtype=torch.float64, device="cuda")
+            # (The reduction that read this output buffer four frames ago is only ENQUEUED on the caller's stream when the buffer is
+            # handed over again — streams share hardware queues, a small kernel there can sit behind whole frames of the context's
+            # own streams.  The first version of the promise covered `out` too and this loop broke it: 8 % of the checksums differed
+            # from run to run.  Since then the kernel that writes `out` waits for the caller's stream position at hand-over.)
             t0 = time.perf_counter()
-            for f in range(a.soak):
-                hl, alpha, nl = plan[f // 97]
-                p = pkg.reference_defaults().set(temporal_enable=1, spatial_enable=1, atrous_nlevel=nl, history_level=hl, color_alpha=alpha,
-                                                 inputs_ready=1 if mode == "pipelined" else 0)
-                d.denoise(ob[f & 3], di[f % nsrc], dg[f % nsrc], cams[f % nsrc], p, stream=stream)
-                if f % 256 == 255:
-                    stream.synchronize()
+            with torch.cuda.stream(stream):
+                for f in range(a.soak):
+                    hl, alpha, nl = plan[f // 97]
+                    p = pkg.reference_defaults().set(temporal_enable=1, spatial_enable=1, atrous_nlevel=nl, history_level=hl, color_alpha=alpha,
+                                                     inputs_ready=1 if mode.startswith("pipelined") else 0)
+                    d.denoise(ob[f & 3], di[f % nsrc], dg[f % nsrc], cams[f % nsrc], p, stream=stream)
+                    o64 = ob[f & 3].double()
+                    chk[f, 0] = o64.sum()
+                    chk[f, 1] = (o64 * o64).sum()
+                    if f % 256 == 255:
+                        stream.synchronize()
             torch.cuda.synchronize()
-            fin[mode] = ([o.cpu().numpy() for o in ob], d.read_state(0), d.read_state(1), d.read_state(2))
+            fin[mode] = ([o.cpu().numpy() for o in ob] + [chk.cpu().numpy()], d.read_state(0), d.read_state(1), d.read_state(2))
             print(f"soak {mode}: {a.soak} frames in {time.perf_counter() - t0:.2f} s, pipelined context: {d.is_pipelined()}", flush=True)
             d.free()
         ok = all(np.array_equal(x, y) for x, y in zip(fin["ordered"][0], fin["pipelined"][0])) and all(np.array_equal(x, y) for x, y in zip(fin["ordered"][1:], fin["pipelined"][1:]))
-        print(f"soak: last four outputs, history lengths, moments and colour history after {a.soak} frames equal bit for bit: {ok}")
+        for x, y in (("ordered", "ordered2"), ("pipelined", "pipelined2"), ("ordered", "pipelined")):
+            bad = np.nonzero((fin[x][0][4] != fin[y][0][4]).any(axis=1))[0]
+            print(f"  {x} vs {y}: {len(bad)} frames differ; first {bad[:12].tolist()}; plan of the first: {plan[bad[0] // 97] if len(bad) else None}; "
+                  f"rel diff of the first: {abs(fin[x][0][4][bad[0], 0] - fin[y][0][4][bad[0], 0]) / abs(fin[x][0][4][bad[0], 0]) if len(bad) else 0:.3e}")
+        nbad = int((fin["ordered"][0][4] != fin["pipelined"][0][4]).any(axis=1).sum())
+        print(f"soak: per-frame checksums of all {a.soak} outputs, last four outputs, history lengths, moments and colour history equal bit for bit: {ok} "
+              f"({nbad} frames with a differing checksum)")
         return
     NCHK = 12
     res = {}
