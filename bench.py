@@ -206,6 +206,12 @@ def main():
     a = ap.parse_args()
 
     # the CPU-baseline leg: one OpenMP thread per physical core, pinned (read by libgomp when the oracle library is loaded)
+    # The frame pipeline wants its two internal streams on hardware queues of their own.  The HIP runtime spreads a process's streams
+    # over GPU_MAX_HW_QUEUES queues (default 4): enough for a plain process, not once RCCL has created its streams (every multi-GPU
+    # rank) — the pipelined frames then share a queue and gain nothing (measured: 0.259 against 0.237 ms per frame with 8 queues,
+    # profiles/r05_exp_pipeline.log).  Read by the runtime at initialisation, so it is set before torch is imported; a value from
+    # the environment wins.
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     os.environ.setdefault("OMP_PLACES", "cores")
     os.environ.setdefault("OMP_PROC_BIND", "spread")     # one thread per core, spread over the CCDs: the oracle lives in L3 (close: 5.2, spread: 8.7 Mpix/s at 16 threads)
 
@@ -311,6 +317,11 @@ def main():
     out = outs[0]
     den = pkg.Denoiser(W, H, device=local_rank)
     stream = torch.cuda.current_stream(dev)
+    # the ordered twin: a second context whose frames are never promised (latency leg, ordered leg, and the fallback below)
+    den_o, op = den, params
+    if pipeline:
+        den_o = pkg.Denoiser(W, H, device=local_rank)
+        op = pkg.SvgfParams.from_buffer_copy(params).set(inputs_ready=0)
     PROFILE_STRIDE = 10     # an event pair attached to every kernel dispatch of every 10th timed step (a timed frame runs ~25 us longer)
     den.profile_stride(PROFILE_STRIDE)
     den.profile_enable(a.steps)
@@ -323,13 +334,22 @@ def main():
             den.denoise_planar(out, d_in[0], cams[0], params, stream=stream)
         torch.cuda.synchronize(dev)
 
+    cur = {"den": den, "params": params}      # what the timed steps run on (the pipeline trial below may swap in the ordered twin)
+
     def step(i):
         k = i % nsrc
         if a.planar_inputs:
-            den.denoise_planar(out, d_in[k], cams[k], params, stream=stream)
+            cur["den"].denoise_planar(out, d_in[k], cams[k], cur["params"], stream=stream)
         else:
-            den.denoise(outs[i & 1], d_in[k], d_g[k], cams[k], params, stream=stream)
+            cur["den"].denoise(outs[i & 1], d_in[k], d_g[k], cams[k], cur["params"], stream=stream)
         return W * H
+
+    def step_ordered(i):
+        k = i % nsrc
+        if a.planar_inputs:
+            den_o.denoise_planar(out, d_in[k], cams[k], op, stream=stream)
+        else:
+            den_o.denoise(outs[i & 1], d_in[k], d_g[k], cams[k], op, stream=stream)
 
     # Clock / power / temperature sampler (tools/telemetry.py): created and started BEFORE the warm-up.  Finding its hwmon node
     # (a sysfs walk, a device-property query) takes milliseconds; between the warm-up and the timed region that was enough idle
@@ -359,6 +379,32 @@ def main():
         if n_w % 32 == 0:
             torch.cuda.synchronize(dev)
     torch.cuda.synchronize(dev)
+    # The pipeline needs its two internal streams on different hardware queues of the HIP runtime (GPU_MAX_HW_QUEUES, default 4: it
+    # works; with 1 or 2 the streams share a queue and the pipelined frames come out 8-10 % SLOWER than ordered ones,
+    # profiles/r05_exp_pipeline.log).  A short trial in the sustained state decides which way the timed steps run.
+    pipeline_trial = None
+    pipeline = pipeline and den.is_pipelined()      # the library takes the promise up only where frames have something to overlap
+    if pipeline:
+        def burst(fn, n=48):
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for i in range(n):
+                fn(i)
+            torch.cuda.synchronize(dev)
+            return (time.perf_counter() - t0) / n * 1e3
+        burst(step_ordered, 16)
+        t_ord = min(burst(step_ordered), burst(step_ordered))
+        burst(step, 16)
+        t_pipe = min(burst(step), burst(step))
+        pipeline_trial = {"pipelined_ms": round(t_pipe, 5), "ordered_ms": round(t_ord, 5), "frames_each": 48}
+        if t_pipe > 0.99 * t_ord:      # no gain here: time the ordered twin instead (and say so)
+            pipeline = False
+            cur["den"], cur["params"] = den_o, op
+            den_o.profile_stride(PROFILE_STRIDE)
+            for i in range(64):
+                step(i)
+            torch.cuda.synchronize(dev)
+    den_first, den = den, cur["den"]
     t_warm_end = time.perf_counter()
     den.profile_enable(a.steps)
     t_region0 = time.perf_counter()
@@ -390,18 +436,6 @@ def main():
     # of its own whose frames are ordered on the stream — in a pipelined context the four cross-stream events of a frame cost such a
     # caller 16 us per call (0.271 -> 0.287 ms, profiles/r05_exp_pipeline.log) and buy it nothing.
     den.profile_enable(0)
-    pipeline = pipeline and den.is_pipelined()      # the library takes the promise up only where frames have something to overlap
-    den_o, op = den, params
-    if pipeline:
-        den_o = pkg.Denoiser(W, H, device=local_rank)
-        op = pkg.SvgfParams.from_buffer_copy(params).set(inputs_ready=0)
-
-    def step_ordered(i):
-        k = i % nsrc
-        if a.planar_inputs:
-            den_o.denoise_planar(out, d_in[k], cams[k], op, stream=stream)
-        else:
-            den_o.denoise(outs[i & 1], d_in[k], d_g[k], cams[k], op, stream=stream)
     for i in range(10):
         step_ordered(i); den_o.sync()
     lat = []
@@ -433,7 +467,6 @@ def main():
             den_o.denoise(outs[i & 1], d_in[i % nsrc], d_g[i % nsrc], cams[i % nsrc], op, stream=stream)
         torch.cuda.synchronize(dev)
         ordered_ms = (time.perf_counter() - t_o) / a.steps * 1e3
-        den_o.free()
 
     # the same kernels with EVERY launch of 16 consecutive frames timed (outside the timed region, sustained clock state)
     iso_params = pkg.reference_defaults().set(temporal_enable=1, spatial_enable=1, atrous_nlevel=NLEVEL, history_level=1)
@@ -503,7 +536,7 @@ def main():
             "cold_is": "frames 2-13 of the process", "first_frame_ms": round(first_frame_ms, 3),
             # the frame pipeline (SvgfParams::inputs_ready, include/svgf.h): consecutive frames of the sequence on two internal streams.
             # `ordered`: the same K steps of this process with every frame ordered on the one stream (round 4's way; rank 0)
-            "frame_pipeline": pipeline,
+            "frame_pipeline": pipeline, "frame_pipeline_trial": pipeline_trial,
             "ordered": ({"ms_per_step": round(ordered_ms, 5), "value": round(W * H / ordered_ms / 1e3, 2), "unit": "Mpixels/s",
                          "what": "the same steps on a second context with SvgfParams::inputs_ready = 0 (every frame ordered on the one stream), after their own 0.4 s of warm-up; rank 0"} if ordered_ms else None),
             "per_rank": per_rank,
@@ -570,7 +603,8 @@ def main():
             else:
                 line["cpu_baseline"] = cpu_baseline(pkg, host_frames, params)
         print(json.dumps(line), flush=True)
-    den.free()
+    for dd in {id(x): x for x in (den, den_o, den_first)}.values():
+        dd.free()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
