@@ -2,10 +2,11 @@
 
 A frame's temporal pass needs of the previous frame only what exists once the level that feeds the colour history has run (level 1 with
 the reference's defaults, src/denoise.cu:391); levels 2-5 of frame n and the temporal pass + level 1 of frame n+1 are independent.  A
-caller that promises `inputs_ready` (inputs complete and `out` free at call time) lets the library run even and odd frames on two
+caller that promises `inputs_ready` (inputs complete at call time) lets the library run even and odd frames on two
 internal streams with two plane sets; the kernels are the same, the data are the same, so every result must be BIT-IDENTICAL to the
 same frames ordered on one stream — for every position of the history level, across mode switches, debug views, non-temporal frames,
-resets, on odd sizes, and under a stream capture (which the pipeline joins instead of escaping).
+resets, on odd sizes, under a stream capture, on two caller streams used in turn without any promise (inputs_ready = 2), and with
+readers of a reused output buffer enqueued behind earlier calls.
 (tests/test_parity_gpu.py::test_back_to_back_asynchronous_frames_equal_synchronised_frames covers history levels 0 / 1 / 3 / 5 at
 1920x1080 with the state read-back.)"""
 import ctypes
@@ -94,8 +95,8 @@ def test_pipelined_1080p_sequence_matches_the_oracle(pkg, orc):
 
 
 def test_a_pipelined_context_joins_a_stream_capture(pkg):
-    """Under hipStreamBeginCapture nothing can be promised: the frame's internal stream waits for the capturing stream (fork) and
-    the capturing stream waits for the frame's end (join), so the whole frame is part of the graph.  Two frames per graph (plane
+    """Under hipStreamBeginCapture nothing can be promised: the frames of a pipelined context are recorded on the capturing stream
+    itself, so the whole frame is part of the graph.  Two frames per graph (plane
     parities), replayed three times, against the same eight frames run eagerly."""
     import torch
     for ln in open("/proc/self/maps"):
