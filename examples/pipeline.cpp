@@ -10,7 +10,7 @@
 // buffers — and SvgfParams::inputs_ready = 2 ("pipeline, ordered behind the stream I pass"): a frame is rendered and denoised on
 // its stream in stream order, what reads its output goes behind the call on the same stream, and the stream only ever waits for the
 // frames that were given to it.  No events, no host synchronisation, no promise about buffers: plain stream semantics.  (With ONE
-// stream the same overlap needs the promise inputs_ready = 1 — inputs complete and output free at call time — which is what
+// stream the same overlap needs the promise inputs_ready = 1 — the inputs are complete at call time — which is what
 // bench.py, whose inputs are resident, makes.)
 //
 //   hipcc --offload-arch=gfx950 -O2 -I include examples/pipeline.cpp -L cuda-path-tracer-denoising_amd -lsvgf_hip \
