@@ -200,6 +200,11 @@ def main():
                     help="SURVEY.md 8f row f1: the producer writes the G-buffer straight into the denoiser's planes (svgf_planar_gbuffer / "
                          "svgf_denoise_planar) instead of handing over 52-byte AoS texels; static-camera configs only (the planes of "
                          "both history parities are filled once, before the timed region, like the AoS inputs)")
+    ap.add_argument("--cadence-hz", type=float, default=60.0,
+                    help="also measure the state an interactive renderer lives in (N = 1 only): producer + svgf_denoise + display pack once per "
+                         "1/Hz seconds with the GPU idle in between, timed by HIP events around the denoise; 0 = skip the leg")
+    ap.add_argument("--cadence-frames", type=int, default=40)
+    ap.add_argument("--trial-reps", type=int, default=3, help="pipelined / ordered regions of --steps frames each, alternating, that decide which way the timed steps run")
     ap.add_argument("--min-warmup-seconds", type=float, default=0.6,
                     help="untimed steps continue after --warmup until this much wall time has passed (clock ramp, history "
                          "fill): a --steps 20 run then measures what a --steps 200 run measures")
@@ -315,7 +320,16 @@ def main():
     cams = [pkg.SvgfCamera.from_dict(c) for c in cam_dicts]
     outs = [torch.empty((H, W, 3), dtype=torch.float32, device=dev) for _ in range(2)]      # alternate: frame n+1 may write while frame n still does
     out = outs[0]
-    den = pkg.Denoiser(W, H, device=local_rank)
+    # the pipelined context is CREATED pipelined (svgf_create_ex: second plane set, internal streams, hardware-queue probe): no frame
+    # of the sequence allocates or synchronises.  The library refuses the promise when its two streams share a hardware queue.
+    t_cr = time.perf_counter()
+    den = pkg.Denoiser(W, H, device=local_rank, pipelined=pipeline)
+    create_ms = (time.perf_counter() - t_cr) * 1e3
+    pipeline_status = den.pipeline_status()
+    pipeline_refused = den.last_error() if (pipeline and pipeline_status != 1) else None
+    pipeline = pipeline and pipeline_status == 1
+    if not pipeline:
+        params.set(inputs_ready=0)
     stream = torch.cuda.current_stream(dev)
     # the ordered twin: a second context whose frames are never promised (latency leg, ordered leg, and the fallback below)
     den_o, op = den, params
@@ -363,7 +377,7 @@ def main():
     # the first 12 frames of the process (cold: clocks and socket power not ramped yet): timed, part of the warm-up
     torch.cuda.synchronize(dev)
     t_f0 = time.perf_counter()
-    step(0)               # the very first frame: kernel code load and, with the frame pipeline, its one-time plane allocation + device sync
+    step(0)               # the very first frame: kernel code load (the pipeline's planes and streams exist since svgf_create_ex)
     torch.cuda.synchronize(dev)
     first_frame_ms = (time.perf_counter() - t_f0) * 1e3
     t_c0 = time.perf_counter()
@@ -379,37 +393,64 @@ def main():
         if n_w % 32 == 0:
             torch.cuda.synchronize(dev)
     torch.cuda.synchronize(dev)
-    # The pipeline needs its two internal streams on different hardware queues of the HIP runtime (GPU_MAX_HW_QUEUES, default 4: it
-    # works; with 1 or 2 the streams share a queue and the pipelined frames come out 8-10 % SLOWER than ordered ones,
-    # profiles/r05_exp_pipeline.log).  A short trial in the sustained state decides which way the timed steps run.
+    # Which way do the timed steps run?  A trial with the timed region's OWN estimator: regions of exactly --steps frames between two
+    # synchronisations, same profiling stride — --trial-reps consecutive regions of each way, each way behind 0.25 s of its own frames
+    # back to back; the pipeline runs only if its MEDIAN region beats the ordered median by >= 3 %.  Then the chosen way runs for
+    # another 0.3 s before the timed region.  Both settling stretches matter: the socket's power controller reacts to a CHANGE of load
+    # within tens of milliseconds — 20 timed steps right behind a trial that alternated 5 ms of ordered and 5 ms of pipelined frames ran
+    # at 0.268-0.273 ms while the regions before them ran at 0.242 and the regions 30 ms later at 0.243 (profiles/r06_bench_settle.log);
+    # round 5's trial (minimum of two 48-frame bursts, 1 % margin) said 0.249 against 0.267 on the driver's box and the timed steps
+    # then ran at 0.270 against 0.268 ordered.
+    def region(fn, n):
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for i in range(n):
+            fn(i)
+        torch.cuda.synchronize(dev)
+        return (time.perf_counter() - t0) / n * 1e3
+
+    def step_pipe(i):
+        k = i % nsrc
+        den.denoise(outs[i & 1], d_in[k], d_g[k], cams[k], params, stream=stream)
+
+    def settle(fn, seconds):
+        t, k = time.perf_counter(), 0
+        while time.perf_counter() - t < seconds:
+            fn(k)
+            k += 1
+            if k % 32 == 0:
+                torch.cuda.synchronize(dev)
+        torch.cuda.synchronize(dev)
+
     pipeline_trial = None
-    pipeline = pipeline and den.is_pipelined()      # the library takes the promise up only where frames have something to overlap
     if pipeline:
-        def burst(fn, n=48):
-            torch.cuda.synchronize(dev)
-            t0 = time.perf_counter()
-            for i in range(n):
-                fn(i)
-            torch.cuda.synchronize(dev)
-            return (time.perf_counter() - t0) / n * 1e3
-        burst(step_ordered, 16)
-        t_ord = min(burst(step_ordered), burst(step_ordered))
-        burst(step, 16)
-        t_pipe = min(burst(step), burst(step))
-        pipeline_trial = {"pipelined_ms": round(t_pipe, 5), "ordered_ms": round(t_ord, 5), "frames_each": 48}
-        if t_pipe > 0.99 * t_ord:      # no gain here: time the ordered twin instead (and say so)
+        den_o.profile_stride(PROFILE_STRIDE)
+        den_o.profile_enable(a.steps)
+        tr_o, tr_p = [], []
+        settle(step_ordered, 0.25)
+        for _ in range(max(1, a.trial_reps)):
+            den_o.profile_enable(a.steps); tr_o.append(region(step_ordered, a.steps))
+        settle(step_pipe, 0.25)
+        for _ in range(max(1, a.trial_reps)):
+            den.profile_enable(a.steps); tr_p.append(region(step_pipe, a.steps))
+        m_o, m_p = float(np.median(tr_o)), float(np.median(tr_p))
+        pipeline_trial = {"pipelined_ms": [round(t, 5) for t in tr_p], "ordered_ms": [round(t, 5) for t in tr_o],
+                          "pipelined_median_ms": round(m_p, 5), "ordered_median_ms": round(m_o, 5), "frames_each": a.steps,
+                          "rule": "pipelined iff its median region <= 0.97 x the ordered median (consecutive regions of --steps frames, each way behind 0.25 s of its own frames)"}
+        if m_p > 0.97 * m_o:      # not worth it on this box: the timed steps run ordered (and the line says so)
             pipeline = False
             cur["den"], cur["params"] = den_o, op
-            den_o.profile_stride(PROFILE_STRIDE)
-            for i in range(64):
-                step(i)
-            torch.cuda.synchronize(dev)
+        settle(step, 0.3)         # the chosen way, back to back, right up to the timed region
     den_first, den = den, cur["den"]
     t_warm_end = time.perf_counter()
     den.profile_enable(a.steps)
     t_region0 = time.perf_counter()
     dt, pixels = pkg.farm.timed_region(step, a.steps, 0, lambda: torch.cuda.synchronize(dev), dist=dist, device=None if share_device else dev)
     t_region1 = time.perf_counter()
+    if os.environ.get("SVGF_BENCH_DEBUG"):
+        dbg = [region(step, a.steps) for _ in range(4)]
+        dbg2 = [pkg.farm.timed_region(step, a.steps, 0, lambda: torch.cuda.synchronize(dev), dist=dist, device=None if share_device else dev)[0] / a.steps * 1e3 for _ in range(3)]
+        print(f"[debug] timed {dt / a.steps * 1e3:.4f}; 4 more regions: {dbg}; 3 more timed_region: {dbg2}", file=sys.stderr)
     # every rank's own clock around its own K steps (the reduction above keeps only the maximum), its device and its CPU slice
     mine = {"rank": rank, "device": local_rank, "device_name": torch.cuda.get_device_name(dev), "ms_per_step": round(pkg.farm.last_local_seconds() / a.steps * 1e3, 5),
             "cpus": cpus_of_rank}
@@ -450,49 +491,102 @@ def main():
     if not (np.isfinite(outs[0].sum().item()) and np.isfinite(outs[1].sum().item())):
         raise SystemExit("bench: non-finite output")
 
-    # the same K steps with every frame ORDERED on the stream (no promise), behind its own sustained warm-up: what the pipeline buys
-    # (on the second context, which never becomes pipelined: an ordered frame of a pipelined context pays the pipeline's events as well)
-    ordered_ms = None
-    if pipeline:
+    # The OTHER leg, beside the headline: the same --steps frames the other way (ordered if the timed steps ran pipelined, pipelined if
+    # they ran ordered), an identical region behind its own stretch of back-to-back frames (the latency loop above idles the GPU).
+    other_leg = None
+    if pipeline_trial is not None:
+        other_is_ordered = pipeline
+        fn_other = step_ordered if other_is_ordered else step_pipe
         t_o = time.perf_counter()
         i = 0
         while time.perf_counter() - t_o < 0.4:
-            den_o.denoise(outs[i & 1], d_in[i % nsrc], d_g[i % nsrc], cams[i % nsrc], op, stream=stream)
+            fn_other(i)
             i += 1
             if i % 32 == 0:
                 torch.cuda.synchronize(dev)
-        torch.cuda.synchronize(dev)
-        t_o = time.perf_counter()
-        for i in range(a.steps):
-            den_o.denoise(outs[i & 1], d_in[i % nsrc], d_g[i % nsrc], cams[i % nsrc], op, stream=stream)
-        torch.cuda.synchronize(dev)
-        ordered_ms = (time.perf_counter() - t_o) / a.steps * 1e3
+        (den_o if other_is_ordered else den_first).profile_stride(PROFILE_STRIDE)
+        (den_o if other_is_ordered else den_first).profile_enable(a.steps)
+        t_oth0 = time.perf_counter()
+        other_ms = region(fn_other, a.steps)
+        t_oth1 = time.perf_counter()
+        other_leg = {"ms_per_step": round(other_ms, 5), "value": round(W * H / other_ms / 1e3, 2), "unit": "Mpixels/s",
+                     "telemetry": tm_all.summary(t_oth0, t_oth1),
+                     "what": ("the same steps with every frame ORDERED on the one stream (a second context, inputs_ready = 0)" if other_is_ordered else
+                              "the same steps PIPELINED (inputs_ready = 1 on the context created with SVGF_CREATE_PIPELINED)")
+                             + ": one region of --steps frames between two synchronisations, after 0.4 s of the same frames; rank 0"}
 
     # the same kernels with EVERY launch of 16 consecutive frames timed (outside the timed region, sustained clock state)
     iso_params = pkg.reference_defaults().set(temporal_enable=1, spatial_enable=1, atrous_nlevel=NLEVEL, history_level=1)
     iso_params.set(kernel_variant=a.kernel_variant)
     if a.config == "config1":
         iso_params.set(temporal_enable=0, atrous_nlevel=1)
-    den.profile_stride(1)
-    den.profile_enable(16)
+    den_o.profile_stride(1)
+    den_o.profile_enable(16)
     for i in range(256):      # back into the sustained clock state (the latency loop above idles the GPU between calls: DESIGN.md 6.2)
-        den.denoise(out, d_in[i % nsrc], d_g[i % nsrc], cams[i % nsrc], iso_params, stream=stream)
+        den_o.denoise(out, d_in[i % nsrc], d_g[i % nsrc], cams[i % nsrc], iso_params, stream=stream)
     torch.cuda.synchronize(dev)
-    den.profile_enable(16)    # same slot count: counters restart, no event is re-created, no idle time
+    den_o.profile_enable(16)    # same slot count: counters restart, no event is re-created, no idle time
     t_iso0 = time.perf_counter()
     for i in range(16):
-        den.denoise(out, d_in[i % nsrc], d_g[i % nsrc], cams[i % nsrc], iso_params, stream=stream)
+        den_o.denoise(out, d_in[i % nsrc], d_g[i % nsrc], cams[i % nsrc], iso_params, stream=stream)
     torch.cuda.synchronize(dev)
     t_iso1 = time.perf_counter()
-    tm_all.stop()
-    iso_atrous_ms = [ms for s in range(den.profile_frames()) for kind, ms in den.profile_read(s)
+    iso_atrous_ms = [ms for s in range(den_o.profile_frames()) for kind, ms in den_o.profile_read(s)
                      if kind == pkg.binding.KERNEL_ATROUS]
+    iso_temporal_ms = [ms for s in range(den_o.profile_frames()) for kind, ms in den_o.profile_read(s)
+                       if kind == pkg.binding.KERNEL_TEMPORAL]
+    iso_fused_ms = [ms for s in range(den_o.profile_frames()) for kind, ms in den_o.profile_read(s) if kind == pkg.binding.KERNEL_FUSED]
+    den_o.profile_enable(0)
+
+    # The state an interactive renderer lives in: one frame per 1/Hz seconds — producer (svgf_synth_render), svgf_denoise, display pack
+    # (svgf_display_pack) enqueued together, the GPU idle until the next tick.  After >= 5 ms of idle time the socket has left its
+    # sustained state and the same kernels run 7-18 % longer.  Timed by HIP events around the denoise and around
+    # the whole frame, on the launch stream.
+    cadence = None
+    if a.cadence_hz > 0 and world == 1 and not a.planar_inputs and a.config != "4k-room":
+        pbo = torch.empty((H, 2 * W, 4), dtype=torch.uint8, device=dev)
+        c_in = torch.empty((H, W, 3), dtype=torch.float32, device=dev)
+        c_g = torch.empty((H * W * 52,), dtype=torch.uint8, device=dev)
+        ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(a.cadence_frames)]
+        period = 1.0 / a.cadence_hz
+        torch.cuda.synchronize(dev)
+        t_cad0 = time.perf_counter()
+        nxt = t_cad0
+        host_ms = []
+        for f in range(a.cadence_frames):
+            while time.perf_counter() < nxt:
+                time.sleep(0.0002)
+            nxt += period
+            k = f % nsrc
+            th0 = time.perf_counter()
+            ev[f][0].record(stream)
+            pkg.binding.synth_render(c_in, c_g, W, H, cam_dicts[k], f, seed=1000 + seq, device=local_rank, stream=stream)
+            ev[f][1].record(stream)
+            den_o.denoise(out, c_in, c_g, cams[k], op, stream=stream)
+            ev[f][2].record(stream)
+            pkg.binding.display_pack(pbo, c_in, out, W, H, device=local_rank, stream=stream)
+            ev[f][3].record(stream)
+            den_o.sync_stream(stream)          # the frame is on the screen before the next one starts (a renderer's swap)
+            host_ms.append((time.perf_counter() - th0) * 1e3)
+        t_cad1 = time.perf_counter()
+        den_ms = [ev[f][1].elapsed_time(ev[f][2]) for f in range(4, a.cadence_frames)]
+        frm_ms = [ev[f][0].elapsed_time(ev[f][3]) for f in range(4, a.cadence_frames)]
+        cadence = {"hz": a.cadence_hz, "frames": a.cadence_frames - 4, "ms_per_step": round(float(np.median(den_ms)), 5),
+                   "ms_per_step_p10_p90": [round(float(np.quantile(den_ms, 0.1)), 5), round(float(np.quantile(den_ms, 0.9)), 5)],
+                   "frame_ms_producer_denoise_pack": round(float(np.median(frm_ms)), 5),
+                   "host_ms_enqueue_to_done": round(float(np.median(host_ms[4:])), 5),
+                   "telemetry": tm_all.summary(t_cad0, t_cad1),
+                   "what": "one frame per 1/hz s: svgf_synth_render + svgf_denoise (ordered, inputs_ready = 0) + svgf_display_pack on one stream, then the "
+                           "stream is waited for and the GPU idles until the next tick; ms_per_step = HIP events around the svgf_denoise of each "
+                           "frame (median; the first 4 frames dropped): the same kernels as the sustained figure, in the power state "
+                           "an otherwise idle GPU is in (DESIGN.md 6.2)"}
+    tm_all.stop()
     # config1 (non-temporal, ONE level): that level carries the prepare pass in its loader waves (one launch per frame, kind FUSED):
     # it is the a-trous launch of this configuration, timed with the prepare work inside it
     level_is_fused = not atrous_ms and bool(fused_ms)
     if level_is_fused:
         atrous_ms = list(fused_ms)
-        iso_atrous_ms = [ms for s in range(den.profile_frames()) for kind, ms in den.profile_read(s) if kind == pkg.binding.KERNEL_FUSED]
+        iso_atrous_ms = list(iso_fused_ms)
 
     if rank == 0:
         traffic, traffic_note, sq_rec = None, "no PMC record", None
@@ -537,8 +631,8 @@ def main():
             # the frame pipeline (SvgfParams::inputs_ready, include/svgf.h): consecutive frames of the sequence on two internal streams.
             # `ordered`: the same K steps of this process with every frame ordered on the one stream (round 4's way; rank 0)
             "frame_pipeline": pipeline, "frame_pipeline_trial": pipeline_trial,
-            "ordered": ({"ms_per_step": round(ordered_ms, 5), "value": round(W * H / ordered_ms / 1e3, 2), "unit": "Mpixels/s",
-                         "what": "the same steps on a second context with SvgfParams::inputs_ready = 0 (every frame ordered on the one stream), after their own 0.4 s of warm-up; rank 0"} if ordered_ms else None),
+            "frame_pipeline_status": pipeline_status, "frame_pipeline_refused": pipeline_refused, "context_create_ms": round(create_ms, 3),
+            ("ordered" if (pipeline or pipeline_trial is None) else "pipelined"): other_leg,
             "per_rank": per_rank,
             # one svgf_denoise + svgf_sync, median of the calls below (host wall clock around the pair)
             "latency_ms_sync": round(float(np.median(lat_ms)), 5),
@@ -559,21 +653,25 @@ def main():
                                    + "; one independent sequence per GPU", "name": a.config,
                        "width": W, "height": H, "atrous_levels": 1 if a.config == "config1" else NLEVEL,
                        "parallelism": f"replicas{world}" + ("-sharing-one-device(test-only)" if share_device else "")},
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+            # the dominant kernel's OWN figure: every a-trous launch of 16 consecutive ORDERED frames (one kernel at a time on the GPU),
+            # sustained state, the dispatches' own begin / end timestamps — what `rocprofv3 --kernel-trace --stats` of an ordered run
+            # reproduces (profiles/).  The same launches as they ran among the timed steps (with the frame pipeline: sharing the GPU with
+            # the other frame's kernels) are under `timed_region`.
+            "roofline": {"bound": "hbm", "achieved": round(iso_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(iso_gbs / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "traffic_measured_live": False, "traffic_provenance": traffic_note,
                          "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, profiles/pmc_traffic.json (FETCH x2 per MI355X_MICROARCH.md)",
-                         "kernel": "one a-trous level: k_atrous_lane (steps 2-32; k_atrous_strip where the library's cost model prefers it), mean over the level launches of the timed frames; in config1 the one launch per frame that carries the prepare pass in its loader waves", "bytes_per_launch": bytes_px * W * H, "bytes_per_pixel": bytes_px,
-                         "mean_launch_us": round(a_ms * 1e3, 2), "launches_timed": len(atrous_ms),
-                         # with the frame pipeline the kernels of two consecutive frames share the GPU: a launch of the timed region
-                         # lasts longer than the same launch alone ('isolated' below: ordered frames), while more than one is in flight
-                         "kernels_in_flight_mean": round(((0.0 if level_is_fused else sum(atrous_ms)) + sum(temporal_ms) + sum(fused_ms)) / max(1, len(temporal_ms) + len(fused_ms)) / (dt / a.steps * 1e3), 3)
-                                                   if (temporal_ms or fused_ms) else None,
+                         "kernel": "one a-trous level: k_atrous_lane (steps 2-32; k_atrous_strip where the library's cost model prefers it), mean over the level launches of 16 ordered frames; in config1 the one launch per frame that carries the prepare pass in its loader waves", "bytes_per_launch": bytes_px * W * H, "bytes_per_pixel": bytes_px,
+                         "mean_launch_us": round(iso_us, 2), "launches_timed": len(iso_atrous_ms),
                          "launch_includes_fused_prepare_pass": level_is_fused,
-                         "note": ("frame pipeline on: the kernels of consecutive frames overlap, 'achieved' / 'frac' are the launches of the timed region as they ran (sharing the GPU); " if pipeline else "everything ordered on one stream; ")
-                                 + "durations are the dispatches' own begin / end timestamps (HIP events attached by hipExtLaunchKernelGGL on the launch stream, every 10th timed frame); 'isolated' repeats the measurement on every kernel of 16 ORDERED frames (one kernel at a time on the GPU: the kernel's own speed)",
-                         "isolated": {"mean_launch_us": round(iso_us, 2), "achieved": round(iso_gbs, 1),
-                                      "frac": round(iso_gbs / HBM_PEAK_GBS, 4), "launches_timed": len(iso_atrous_ms)},
+                         "note": "durations are the dispatches' own begin / end timestamps (HIP events attached by hipExtLaunchKernelGGL on the launch stream); frac x peak x mean_launch_us = bytes_per_launch",
+                         "timed_region": {"mean_launch_us": round(a_ms * 1e3, 2), "achieved": round(achieved, 1), "frac": round(achieved / HBM_PEAK_GBS, 4),
+                                          "launches_timed": len(atrous_ms), "every_kth_frame": PROFILE_STRIDE,
+                                          # with the frame pipeline the kernels of two consecutive frames share the GPU: a launch of the timed
+                                          # region lasts longer than the same launch alone, while more than one is in flight
+                                          "kernels_in_flight_mean": round(((0.0 if level_is_fused else sum(atrous_ms)) + sum(temporal_ms) + sum(fused_ms)) / max(1, len(temporal_ms) + len(fused_ms)) / (dt / a.steps * 1e3), 3)
+                                                                    if (temporal_ms or fused_ms) else None,
+                                          "note": ("frame pipeline on: the kernels of consecutive frames overlap" if pipeline else "everything ordered on one stream")},
                          # the secondary limiter.  24 taps x (2 v_sqrt + 1 v_exp) + 5 (centre, normalisation) per pixel-level
                          "transcendental_gops_isolated": round(77 * W * H / (iso_us * 1e-6) / 1e9, 1),
                          "transcendental_gops_isolated_is": "a formula, not a counter: 77 transcendental operations per pixel-level x pixels / the isolated launch duration",
@@ -587,9 +685,14 @@ def main():
                                        "simd_instruction_active_pmc": sq_rec["simd_instruction_active_mean"] if sq_rec else None,
                                        "simd_instruction_active_pmc_source": (f"profiles/pmc_traffic.json sq_activity[{W}x{H}] ({', '.join(sq_rec['source_files'])}; sclk {sq_rec['sclk_mhz']:.0f} MHz)"
                                                                               if sq_rec else "no SQ pass recorded for these kernel sources at this size")}},
-            "kernels_us": {"temporal": round(float(np.mean(temporal_ms)) * 1e3, 2) if temporal_ms else None,
+            # the kernels' own durations (16 ordered frames, as `roofline`); `kernels_us_timed_region`: as they ran among the timed steps
+            "kernels_us": {"temporal": round(float(np.mean(iso_temporal_ms)) * 1e3, 2) if iso_temporal_ms else None,
+                           "fused_prepare_plus_level1": round(float(np.mean(iso_fused_ms)) * 1e3, 2) if iso_fused_ms else None,
+                           "atrous_level_mean": round(iso_us, 2)},
+            "kernels_us_timed_region": {"temporal": round(float(np.mean(temporal_ms)) * 1e3, 2) if temporal_ms else None,
                            "fused_prepare_plus_level1": round(float(np.mean(fused_ms)) * 1e3, 2) if fused_ms else None,
                            "atrous_level_mean": round(a_ms * 1e3, 2), "atrous_launches_per_frame": round(len(atrous_ms) / max(1, len(fused_ms) + len(temporal_ms)), 2) if (fused_ms or temporal_ms) else None},
+            "cadence": cadence,
             "frame_algorithmic_gbs": round((bytes_px if a.config == "config1" else FRAME_BYTES_PER_PIXEL)
                                            * W * H / (dt / a.steps) / 1e9 / world * 1.0, 1),
         }

@@ -31,7 +31,9 @@ EXPORTS = ["svgf_version", "svgf_params_default", "svgf_create", "svgf_destroy",
            "svgf_set_capture", "svgf_profile_enable", "svgf_profile_stride", "svgf_profile_frames", "svgf_profile_read",
            "svgf_synth_camera", "svgf_synth_render", "svgf_scene_render", "svgf_scene_render_mesh", "svgf_display_pack", "svgf_save_png",
            "svgf_planar_gbuffer", "svgf_denoise_planar", "svgf_synth_render_planar", "svgf_params_sizeof", "svgf_scene_render_mesh_planar",
-           "svgf_sync_stream", "svgf_build_has_experiments", "svgf_is_pipelined"]
+           "svgf_sync_stream", "svgf_build_has_experiments", "svgf_is_pipelined", "svgf_create_ex", "svgf_enable_pipeline",
+           "svgf_pipeline_status"]
+CREATE_PIPELINED = 1
 
 
 class SvgfCamera(C.Structure):
@@ -89,12 +91,14 @@ class SvgfError(RuntimeError):
 
 _lib = None
 _lib_exp = None
-# tuning knobs of the experiments build that tools/experiments/*.sh pass as environment variables: forwarded to svgf_exp_set()
-# when the experiments library is loaded (the C library itself reads no environment variable)
-_EXP_ENV = {"SVGF_LANE_SEGROWS": "lane_segrows", "SVGF_LANE_DBG": "lane_dbg", "SVGF_LANE_DBG_SKIP": "lane_dbg_skip",
-            "SVGF_STRIP_SEGROWS": "strip_segrows", "SVGF_STRIP_FIXED_ROWS": "strip_fixed_rows", "SVGF_STRIP_TX": "strip_tx",
-            "SVGF_STRIP_ROWS": "strip_rows", "SVGF_STRIP_DBG": "strip_dbg", "SVGF_STRIP_DBG_SKIP": "strip_dbg_skip",
-            "SVGF_NO_VARIANCE_PLANE": "no_variance_plane", "SVGF_REUSE": "reuse", "SVGF_SPLIT_FUSED": "split_fused"}
+_default_experiments = False
+
+
+def use_experiments_library(on: bool = True):
+    """Tests / tools of parked experiments: make libsvgf_hip_exp.so the library every following Denoiser / producer call of this
+    process uses (an explicit call — the binding reads no environment variable; the product path never calls this)."""
+    global _default_experiments
+    _default_experiments = bool(on)
 
 
 def exp_set(name: str, value: int):
@@ -109,20 +113,15 @@ def exp_clear():
 
 
 def load_library(path: str | None = None, experiments: bool = False):
-    """Load libsvgf_hip.so (or, experiments=True, libsvgf_hip_exp.so) and declare prototypes.  Fails loudly when the library is
-    absent.  SVGF_USE_EXPERIMENTS_LIB=1 in the environment makes the experiments build the default of this PYTHON binding
-    (tools/experiments/*.sh); the product path never sets it."""
+    """Load libsvgf_hip.so (or, experiments=True / after use_experiments_library(), libsvgf_hip_exp.so) and declare prototypes.
+    Fails loudly when the library is absent.  No environment variable is read."""
     global _lib, _lib_exp
-    if path is None and not experiments and os.environ.get("SVGF_USE_EXPERIMENTS_LIB"):
+    if path is None and not experiments and _default_experiments:
         experiments = True
     if path is None and experiments:
         if _lib_exp is None:
             _lib_exp = load_library(LIB_EXP_PATH)
             _lib_exp.svgf_exp_set.argtypes = [C.c_char_p, C.c_int]
-            for env, key in _EXP_ENV.items():
-                if env in os.environ:
-                    v = os.environ[env]
-                    _lib_exp.svgf_exp_set(key.encode(), int(v) if v.lstrip("-").isdigit() else 1)
         return _lib_exp
     if _lib is not None and path is None:
         return _lib
@@ -143,6 +142,10 @@ def load_library(path: str | None = None, experiments: bool = False):
     lib.svgf_version.restype = ip
     lib.svgf_params_default.argtypes = [C.POINTER(SvgfParams)]
     lib.svgf_create.argtypes = [ip, ip, ip, C.POINTER(vp)]
+    lib.svgf_create_ex.argtypes = [ip, ip, ip, C.c_uint, C.POINTER(vp)]
+    lib.svgf_enable_pipeline.argtypes = [vp]
+    lib.svgf_pipeline_status.argtypes = [vp]
+    lib.svgf_pipeline_status.restype = ip
     lib.svgf_destroy.argtypes = [vp]
     lib.svgf_reset.argtypes = [vp]
     lib.svgf_denoise.argtypes = [vp, vp, vp, vp, C.POINTER(SvgfCamera), C.POINTER(SvgfParams), vp]
@@ -199,16 +202,18 @@ def _ptr(x):
 class Denoiser:
     """One SVGF context on one GPU (denoiseInit .. denoiseFree of the reference, handle-based)."""
 
-    def __init__(self, width: int, height: int, device: int = 0, experiments: bool = False):
-        """experiments=True: the context lives in libsvgf_hip_exp.so (kernel_variant 5 / 6, exp_set knobs) — tests and tools only."""
+    def __init__(self, width: int, height: int, device: int = 0, experiments: bool = False, pipelined: bool = False):
+        """pipelined=True: svgf_create_ex(SVGF_CREATE_PIPELINED) — the frame pipeline's resources exist from the start
+        (SvgfParams.inputs_ready is ignored by any other context).
+        experiments=True: the context lives in libsvgf_hip_exp.so (kernel_variant 5 / 6, exp_set knobs) — tests and tools only."""
         self.lib = load_library(experiments=experiments)
         self.width, self.height = int(width), int(height)
         self.ui = SvgfParams()
         self.lib.svgf_params_default(C.byref(self.ui))
         h = C.c_void_p()
-        rc = self.lib.svgf_create(int(device), self.width, self.height, C.byref(h))
+        rc = self.lib.svgf_create_ex(int(device), self.width, self.height, CREATE_PIPELINED if pipelined else 0, C.byref(h))
         if rc != SVGF_OK:
-            raise SvgfError(f"svgf_create({device},{width},{height}) -> {rc}: {self.lib.svgf_last_error(None).decode()}")
+            raise SvgfError(f"svgf_create_ex({device},{width},{height}) -> {rc}: {self.lib.svgf_last_error(None).decode()}")
         self.h = h
 
     def _check(self, rc, what):
@@ -269,8 +274,19 @@ class Denoiser:
         self._check(self.lib.svgf_sync(self.h), "svgf_sync")
 
     def is_pipelined(self) -> bool:
-        """True once a frame with SvgfParams.inputs_ready has switched the context to the frame pipeline (include/svgf.h, ABI 0.8)."""
+        """True while the context's frames alternate between its two plane sets (include/svgf.h: svgf_is_pipelined)."""
         return bool(self.lib.svgf_is_pipelined(self.h))
+
+    def enable_pipeline(self):
+        """svgf_enable_pipeline: create the frame pipeline's resources now (allocates, synchronises the device, probes the queues)."""
+        self._check(self.lib.svgf_enable_pipeline(self.h), "svgf_enable_pipeline")
+
+    def pipeline_status(self) -> int:
+        """0 no resources, 1 promise honoured, 2 promise refused (internal streams share a hardware queue)."""
+        return int(self.lib.svgf_pipeline_status(self.h))
+
+    def last_error(self) -> str:
+        return self.lib.svgf_last_error(self.h).decode()
 
     def sync_stream(self, stream=None):
         """Wait for what has been enqueued on `stream` only (svgf_sync waits for the whole device, as the reference does)."""

@@ -43,7 +43,10 @@ struct svgf_ctx {
     // call.  The kernels of two consecutive frames then share the chip: one frame's level tails, launch gaps and opening bursts
     // lie under the other's tap rows (two INDEPENDENT sequences on two streams: +9-10 % in aggregate,
     // profiles/r05_exp_two_sequences.log — the ceiling of this).
-    int pipelined;
+    int pipelined;         // the second plane set, the internal streams and the events exist (svgf_create_ex / svgf_enable_pipeline)
+    int piped_mode;        // frames alternate between the two plane sets (every frame of the context, once on)
+    int pipe_serial;       // the probe at enable time found the two internal streams on ONE hardware queue: the promise is refused
+    int ever_captured;     // a frame of this context has been recorded into a graph: promised frames order themselves behind `stream`
     hipStream_t pipe[2];
     hipEvent_t ev_hist[2], ev_done[2], ev_in;
     int ev_hist_valid[2];
@@ -251,10 +254,16 @@ static int zero_state(svgf_ctx *c)
     return SVGF_OK;
 }
 
-extern "C" int svgf_create(int device, int width, int height, svgf_ctx **out)
+static int enable_pipeline(svgf_ctx *c);
+
+extern "C" int svgf_create_ex(int device, int width, int height, unsigned flags, svgf_ctx **out)
 {
     if (!out) return SVGF_ERR_INVALID_ARG;
     *out = nullptr;
+    if (flags & ~(unsigned)SVGF_CREATE_PIPELINED) {
+        snprintf(g_create_err, sizeof(g_create_err), "svgf_create_ex: unknown flags 0x%x", flags);
+        return SVGF_ERR_INVALID_ARG;
+    }
     if (width <= 0 || height <= 0 || (long long)width * height > (1LL << 30)) {
         snprintf(g_create_err, sizeof(g_create_err), "svgf_create: bad size %dx%d", width, height);
         return SVGF_ERR_INVALID_ARG;
@@ -318,9 +327,19 @@ extern "C" int svgf_create(int device, int width, int height, svgf_ctx **out)
         free_all(c); delete c;
         return SVGF_ERR_HIP;
     }
+    if (flags & SVGF_CREATE_PIPELINED) {
+        const int rc = enable_pipeline(c);
+        if (rc != SVGF_OK) {
+            snprintf(g_create_err, sizeof(g_create_err), "%s", c->err);
+            free_all(c); delete c;
+            return rc;
+        }
+    }
     *out = c;
     return SVGF_OK;
 }
+
+extern "C" int svgf_create(int device, int width, int height, svgf_ctx **out) { return svgf_create_ex(device, width, height, 0u, out); }
 
 extern "C" int svgf_destroy(svgf_ctx *c)
 {
@@ -341,7 +360,16 @@ extern "C" int svgf_reset(svgf_ctx *c)
     return zero_state(c);
 }
 
-extern "C" int svgf_is_pipelined(const svgf_ctx *c) { return (c && c->pipelined) ? 1 : 0; }
+extern "C" int svgf_is_pipelined(const svgf_ctx *c) { return (c && c->pipelined && c->piped_mode) ? 1 : 0; }
+extern "C" int svgf_pipeline_status(const svgf_ctx *c) { return !c || !c->pipelined ? 0 : (c->pipe_serial ? 2 : 1); }
+
+extern "C" int svgf_enable_pipeline(svgf_ctx *c)
+{
+    if (!c) return SVGF_ERR_INVALID_ARG;
+    SvgfDeviceGuard dev_guard(c->device);
+    if (!dev_guard.ok) { snprintf(c->err, sizeof(c->err), "hipSetDevice(%d) failed", c->device); return SVGF_ERR_HIP; }
+    return enable_pipeline(c);
+}
 
 extern "C" int svgf_sync(svgf_ctx *c)
 {
@@ -491,21 +519,70 @@ thread_local SvgfLaunchEvents g_svgf_launch_events = { nullptr, nullptr };
 
 // ---- the frame ------------------------------------------------------------------------------------------------
 
-// First frame that asks for the pipeline: the second plane set, two streams, the events.  Allocates and synchronises the device,
-// once per context (not under stream capture: the caller of denoise_frame checks).
-static int ensure_pipeline(svgf_ctx *c)
+// ---- the frame pipeline's resources: second plane set, two internal streams, events; and the probe that decides whether the
+// promise (inputs_ready = 1) can be honoured.  Called by svgf_create_ex(SVGF_CREATE_PIPELINED) or svgf_enable_pipeline, never by
+// svgf_denoise: it allocates and synchronises the device.
+__global__ void k_svgf_spin(unsigned long long ticks)
+{
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+}
+
+// Do kernels on pipe[0] and pipe[1] overlap?  The HIP runtime spreads a process's streams over GPU_MAX_HW_QUEUES hardware queues
+// (default 4, read when the runtime starts); two streams that land on the same queue run their kernels one after the other, and
+// pipelined frames are then 8-10 % SLOWER than ordered ones (the cross-stream events cost, nothing overlaps: profiles/r05_exp_pipeline.log).
+// Two one-wave spin kernels of ~200 us, one per stream: together they take ~200 us on two queues and ~400 us on one.
+static int probe_streams_overlap(svgf_ctx *c, bool *overlap, double *ratio_out)
+{
+    int khz = 0;
+    if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, c->device) != hipSuccess || khz <= 0) khz = 100000;
+    const double spin_us = 200.0;
+    const unsigned long long ticks = (unsigned long long)(spin_us * 1e-6 * khz * 1e3);
+    hipEvent_t e[4];
+    for (int k = 0; k < 4; k++) HIPC(c, hipEventCreate(&e[k]));
+    double best = 1e30;
+    for (int trial = 0; trial < 4; trial++) {       // trial 0 loads the code object
+        HIPC(c, hipDeviceSynchronize());
+        HIPC(c, hipEventRecord(e[0], c->pipe[0]));
+        hipLaunchKernelGGL(k_svgf_spin, dim3(1), dim3(64), 0, c->pipe[0], trial ? ticks : 1ull);
+        HIPC(c, hipEventRecord(e[1], c->pipe[0]));
+        HIPC(c, hipEventRecord(e[2], c->pipe[1]));
+        hipLaunchKernelGGL(k_svgf_spin, dim3(1), dim3(64), 0, c->pipe[1], trial ? ticks : 1ull);
+        HIPC(c, hipEventRecord(e[3], c->pipe[1]));
+        HIPC(c, hipGetLastError());
+        HIPC(c, hipDeviceSynchronize());
+        if (!trial) continue;
+        // span from the earlier start to the later end, on the device's own clock
+        float a01 = 0, a23 = 0, a03 = 0, a21 = 0;
+        HIPC(c, hipEventElapsedTime(&a01, e[0], e[1]));
+        HIPC(c, hipEventElapsedTime(&a23, e[2], e[3]));
+        HIPC(c, hipEventElapsedTime(&a03, e[0], e[3]));
+        HIPC(c, hipEventElapsedTime(&a21, e[2], e[1]));
+        double span = a03 > a21 ? a03 : a21;
+        if (a01 > span) span = a01;
+        if (a23 > span) span = a23;
+        const double one = (a01 < a23 ? a01 : a23);
+        if (one > 0 && span / one < best) best = span / one;
+    }
+    for (int k = 0; k < 4; k++) (void)hipEventDestroy(e[k]);
+    *ratio_out = best;
+    *overlap = best < 1.5;          // 1.0: side by side; 2.0: one after the other
+    return SVGF_OK;
+}
+
+static int enable_pipeline(svgf_ctx *c)
 {
     if (c->pipelined) return SVGF_OK;
     for (int k = 3; k < 6; k++) {
         char *raw = nullptr;
         if (!c->cv[k]) {
-            if (hipMalloc((void **)&raw, c->n * sizeof(float4) + 2 * kPlanePad) != hipSuccess) { snprintf(c->err, sizeof(c->err), "svgf_denoise: hipMalloc failed for the pipeline's planes"); return SVGF_ERR_OOM; }
+            if (hipMalloc((void **)&raw, c->n * sizeof(float4) + 2 * kPlanePad) != hipSuccess) { snprintf(c->err, sizeof(c->err), "svgf_enable_pipeline: hipMalloc failed for the pipeline's planes"); return SVGF_ERR_OOM; }
             c->cv[k] = reinterpret_cast<float4 *>(raw + kPlanePad);
             HIPC(c, hipMemset(raw, 0, c->n * sizeof(float4) + 2 * kPlanePad));
         }
         if (!c->vp[k]) {
             const size_t vb = (size_t)(c->W + 2) * (c->H + 2) * sizeof(float) + 64;
-            if (hipMalloc((void **)&c->vp[k], vb) != hipSuccess) { snprintf(c->err, sizeof(c->err), "svgf_denoise: hipMalloc failed for the pipeline's planes"); return SVGF_ERR_OOM; }
+            if (hipMalloc((void **)&c->vp[k], vb) != hipSuccess) { snprintf(c->err, sizeof(c->err), "svgf_enable_pipeline: hipMalloc failed for the pipeline's planes"); return SVGF_ERR_OOM; }
             HIPC(c, hipMemset(c->vp[k], 0, vb));
         }
     }
@@ -515,10 +592,19 @@ static int ensure_pipeline(svgf_ctx *c)
         if (!c->ev_done[q]) HIPC(c, hipEventCreateWithFlags(&c->ev_done[q], hipEventDisableTiming));
     }
     if (!c->ev_in) HIPC(c, hipEventCreateWithFlags(&c->ev_in, hipEventDisableTiming));
+    bool overlap = true;
+    double ratio = 0.0;
+    if (const int rc = probe_streams_overlap(c, &overlap, &ratio); rc != SVGF_OK) return rc;
     HIPC(c, hipDeviceSynchronize());
     c->pipelined = 1;
+    c->pipe_serial = overlap ? 0 : 1;
+    c->piped_mode = overlap ? 1 : 0;      // (refused: frames stay plain ordered frames until one asks for inputs_ready = 2)
     c->pipe_frames = 0; c->ev_hist_valid[0] = c->ev_hist_valid[1] = 0;
     c->ev_done_valid[0] = c->ev_done_valid[1] = 0;
+    if (!overlap)
+        snprintf(c->err, sizeof(c->err), "frame pipeline: the context's two internal streams share a hardware queue (two 200 us kernels took %.2fx one): "
+                 "the inputs_ready = 1 promise is refused and such frames run ordered on the caller's stream; start the process with "
+                 "GPU_MAX_HW_QUEUES=8 (read by the HIP runtime at initialisation)", ratio);
     return SVGF_OK;
 }
 
@@ -614,10 +700,13 @@ static int denoise_frame(svgf_ctx *c, void *out_rgb_dev, const void *in_rgb_dev,
     // the same overlap with nothing but stream semantics — a stream only ever waits for the frames that were given to it.
     const bool worth = gbuffer_dev != nullptr && p->temporal_enable && p->spatial_enable && p->atrous_nlevel >= 2 &&
                        p->right_view_option != 1 && p->right_view_option != 2 && p->history_level != p->atrous_nlevel;
-    bool promise = (p->inputs_ready == 1) && worth;
-    bool want_pipeline = (p->inputs_ready != 0) && worth;
+    // Only a context whose pipeline resources exist (svgf_create_ex(SVGF_CREATE_PIPELINED) / svgf_enable_pipeline) takes either form up:
+    // svgf_denoise never allocates.  The promise additionally needs the two internal streams on different hardware queues (probed when
+    // the resources were created, svgf_pipeline_status() == 1): refused, a promised frame is a plain ordered frame.
+    bool promise = (p->inputs_ready == 1) && worth && c->pipelined && !c->pipe_serial;
+    bool want_pipeline = promise || ((p->inputs_ready == 2) && worth && c->pipelined);
     unsigned long long cap_id = 0;      // != 0: `stream` is being captured into a graph
-    if (want_pipeline || c->pipelined) {
+    if (want_pipeline || c->piped_mode) {
         hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
         unsigned long long id = 0;
         if (s_user && hipStreamGetCaptureInfo(s_user, &cs, &id) == hipSuccess && cs != hipStreamCaptureStatusNone) { cap_id = id ? id : 1; promise = false; }
@@ -628,8 +717,12 @@ static int denoise_frame(svgf_ctx *c, void *out_rgb_dev, const void *in_rgb_dev,
 #ifdef SVGF_BUILD_EXPERIMENTS
     if (p->kernel_variant == 6 || p->kernel_variant == 5 || c->use_reuse || c->use_split_fused) { promise = false; want_pipeline = false; }
 #endif
-    if (want_pipeline && !cap_id && !c->pipelined) { const int rc = ensure_pipeline(c); if (rc != SVGF_OK) return rc; }
-    const bool piped = c->pipelined != 0;
+    if (want_pipeline && !cap_id && !c->piped_mode) {      // (a state flip, nothing is allocated: the colour history lies in plane set 0)
+        c->piped_mode = 1; c->pipe_frames = 0;
+        c->ev_hist_valid[0] = c->ev_hist_valid[1] = 0; c->ev_done_valid[0] = c->ev_done_valid[1] = 0;
+    }
+    const bool piped = c->piped_mode != 0;
+    if (piped && cap_id) c->ever_captured = 1;
     const int pq = piped ? (int)(c->pipe_frames & 1) : 0;
     const int pbase = piped ? 3 * pq : 0;          // this frame's plane set
     // A promised frame runs on the context's stream of its parity.  Every other frame of a pipelined context runs on the caller's own
@@ -639,7 +732,10 @@ static int denoise_frame(svgf_ctx *c, void *out_rgb_dev, const void *in_rgb_dev,
     if (piped) {
         if (promise) {
             HIPC(c, hipEventRecord(c->ev_in, s_user));      // the caller's stream position at hand-over: the last level waits for it (`out`)
-            if (c->pipe_frames == 0) HIPC(c, hipStreamWaitEvent(s, c->ev_in, 0));      // the first pipelined frame: all of it behind the caller's stream
+            // the first pipelined frame: all of it behind the caller's stream.  So is every promised frame of a context that has ever
+            // been recorded into a graph: a replay of that graph on the caller's stream touches the same planes and is visible to this
+            // frame only through the caller's stream position
+            if (c->pipe_frames == 0 || c->ever_captured) HIPC(c, hipStreamWaitEvent(s, c->ev_in, 0));
         }
         if (c->ev_done_valid[pq] && c->ev_done_cap[pq] == cap_id) HIPC(c, hipStreamWaitEvent(s, c->ev_done[pq], 0));
     }
@@ -727,13 +823,13 @@ static int denoise_frame(svgf_ctx *c, void *out_rgb_dev, const void *in_rgb_dev,
     c->vp_valid &= ~(1u << acc);     // the temporal / prepare pass writes no variance plane: the first level gathers cv.w
     c->acc = acc;
     c->hist = acc;                                   // color_history <- color_acc / input (:366,370)
+    if (c->capture && !fused) { HIPC(c, hipMemcpyAsync(c->cv_capture, c->cv[acc], c->n * sizeof(float4), hipMemcpyDeviceToDevice, s)); }      // (before the early release below: the next frame's copy into the one capture buffer must not overtake this one)
     if (piped && cascade && p->temporal_enable && !(p->history_level >= 1 && p->history_level <= p->atrous_nlevel)) {
         // no level of this cascade writes the colour history: it IS the accumulated plane (which no level of this frame overwrites),
         // and everything else the next temporal pass reads was final before: the other stream may go on behind the temporal pass
         HIPC(c, hipEventRecord(c->ev_hist[pq], s));
         c->ev_hist_valid[pq] = 1; c->ev_hist_cap[pq] = cap_id; hist_event_recorded = true;
     }
-    if (c->capture && !fused) { HIPC(c, hipMemcpyAsync(c->cv_capture, c->cv[acc], c->n * sizeof(float4), hipMemcpyDeviceToDevice, s)); }
 
     // 2) debug views, pass-through or the a-trous cascade (:373-394)
     if (p->right_view_option == 1) {
@@ -904,7 +1000,7 @@ extern "C" int svgf_planar_gbuffer(svgf_ctx *c, SvgfPlanarGBuffer *out)
     // choosing.  On an ordered context that stream has waited for every frame (stream order); frames of a PIPELINED context may still be
     // running on another stream of the caller's or on the context's own, so the hand-out waits for them — the planar path orders its
     // frames anyway (svgf_denoise_planar never pipelines).
-    if (c->pipelined) HIPC(c, hipDeviceSynchronize());
+    if (c->piped_mode) HIPC(c, hipDeviceSynchronize());
     const int gnew = 1 - c->gcur;        // the planes the next frame's temporal / prepare pass treats as "current"
     out->normal = c->nrm[gnew]; out->position = c->pos[gnew]; out->geom_id = c->gid[gnew]; out->albedo = c->albedo;
     return SVGF_OK;

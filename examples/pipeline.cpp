@@ -1,4 +1,4 @@
-// examples/pipeline.cpp — a renderer's frame loop on the frame pipeline (SvgfParams::inputs_ready, include/svgf.h ABI 0.8), in C++
+// examples/pipeline.cpp — a renderer's frame loop on the frame pipeline (SvgfParams::inputs_ready, svgf_create_ex; include/svgf.h ABI 0.9), in C++
 // through the C ABI.
 //
 // The reference renders a frame and denoises it in turn, with a device synchronisation at the end of denoise() (src/pathtrace.cu:436-438,
@@ -36,7 +36,7 @@ static int run(bool pipelined, int frames, int W, int H, std::vector<float> (&la
 {
     const size_t n = (size_t)W * H;
     svgf_ctx *ctx = nullptr;
-    SVGF_OKAY(svgf_create(0, W, H, &ctx));
+    SVGF_OKAY(svgf_create_ex(0, W, H, pipelined ? SVGF_CREATE_PIPELINED : 0u, &ctx));      // the second plane set exists before the first frame
     float *rgb[2], *out[2];
     void *gbuf[2];
     hipStream_t st[2];

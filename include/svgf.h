@@ -32,7 +32,7 @@ extern "C" {
 #endif
 
 #define SVGF_VERSION_MAJOR 0
-#define SVGF_VERSION_MINOR 8
+#define SVGF_VERSION_MINOR 9
 
 /* ---- error codes (every entry point returns one of these; the library never exits) ---- */
 #define SVGF_OK                 0
@@ -95,27 +95,40 @@ typedef struct SvgfParams {
                                  temporal pass fused into the first level — measured losses) that exist only in
                                  the experiments build of these sources (libsvgf_hip_exp.so, -DSVGF_BUILD_EXPERIMENTS): this
                                  library answers SVGF_ERR_UNSUPPORTED, before anything is enqueued. */
-    int   inputs_ready;       /* ABI 0.8: the FRAME PIPELINE.  1 is a promise about THIS call: the inputs (colour, G-buffer) are
-                                 COMPLETE at call time — not merely enqueued on `stream` — and stay untouched until the work of
-                                 this call is done.  The library then does not order the frame behind `stream`: it runs even and
-                                 odd frames on two internal streams with two sets of colour planes, starts a frame's temporal pass
-                                 as soon as the level that feeds the previous frame's colour history has run (history_level 1: the
-                                 previous frame's levels 2-5 and this frame's temporal pass + level 1 share the GPU), lets only
-                                 the kernel that writes `output` wait for what `stream` held at call time (readers of the same
-                                 buffer behind earlier calls), and makes `stream` wait for the frame's end — so what the caller
-                                 enqueues behind the call sees `output`, exactly as without the promise.  Results are bit-identical
-                                 to ordered frames (tests/test_pipeline_gpu.py); 1080p: 0.260 -> 0.238 ms per frame
-                                 (profiles/r05_exp_pipeline.log).  The first promising frame allocates the second plane set
-                                 (3 x 16 B/px + 3 x 4 B/px) and synchronises the device, once.  0 = everything ordered on
-                                 `stream` (the reference's behaviour; such frames of a pipelined context run on `stream` itself).
+    int   inputs_ready;       /* The FRAME PIPELINE (ABI 0.8; explicit resources since 0.9).  Only a context whose pipeline resources
+                                 exist — svgf_create_ex(.., SVGF_CREATE_PIPELINED, ..) or svgf_enable_pipeline(ctx): a second set of colour
+                                 planes (+60 B/px), two internal streams, events — looks at this field; any other context orders every
+                                 frame on `stream`, and svgf_denoise never allocates or synchronises.
+                                 1 is a promise about THIS call: the inputs (colour, G-buffer) are COMPLETE at call time — not merely
+                                 enqueued on `stream` — and stay untouched until the work of this call is done.  The library then does
+                                 not order the frame behind `stream`: it runs even and odd frames on its two internal streams with
+                                 two sets of colour planes, starts a frame's temporal pass as soon as the level that feeds the
+                                 previous frame's colour history has run (history_level 1: the previous frame's levels 2-5 and this
+                                 frame's temporal pass + level 1 share the GPU), lets only the kernel that writes `output` wait for
+                                 what `stream` held at call time (readers of the same buffer behind earlier calls), and makes
+                                 `stream` wait for the frame's end — so what the caller enqueues behind the call sees `output`,
+                                 exactly as without the promise.  Results are bit-identical to ordered frames
+                                 (tests/test_pipeline_gpu.py).  What it is worth depends on the box: +5-10 % at 1080p where the socket
+                                 has power headroom, nothing where the ordered frames already run at the power limit.
+                                 The promise NEEDS the two internal streams on different hardware queues of the HIP runtime
+                                 (GPU_MAX_HW_QUEUES, default 4, read by the runtime when the process starts; a process that also holds
+                                 an RCCL communicator or many streams of its own should export 8): on one queue pipelined frames are
+                                 8-10 % SLOWER than ordered ones.  The library probes this when the resources are created (two 200 us
+                                 kernels, one per stream: side by side or one after the other?) and REFUSES the promise when they
+                                 serialise — svgf_pipeline_status() == 2, svgf_last_error() says why, promised frames run as
+                                 ordinary ordered frames.
+                                 0 = everything ordered on `stream` (the reference's behaviour).
                                  2 = the pipeline WITHOUT the promise: the frame is ordered behind `stream` like any other work
                                  (inputs produced there, output consumed there), and a caller that alternates TWO streams from
                                  frame to frame — each with its own input / output buffers — gets the same overlap from plain
                                  stream semantics, because a stream only waits for the frames that were given to it
                                  (examples/pipeline.cpp: producer + denoiser of consecutive frames overlapping, no events).
                                  Ignored — the frame is ordered on `stream` — on the planar path and while `stream` is being
-                                 captured into a graph.  (ABI 0.6-0.7 ignored the field; rounds 1-3 used
-                                 it for a narrower overlap, the temporal pass alone on a side stream, which lost.) */
+                                 captured into a graph.  Once a frame of the context HAS been captured, promised frames order
+                                 themselves behind `stream` entirely (a replay of the graph on `stream` uses the same planes): mix
+                                 graph replay and the promise only if that is acceptable.  One-launch frames (temporal off, one level)
+                                 and frames whose colour history is the LAST level's output have nothing to overlap and never take
+                                 the pipeline up. */
     float reproj_scale[2];    /* "next" row f4, paper-faithful reprojection: if > 0, the previous-frame clip
                                  coordinate is divided by it before the ndc mapping: (tan(FOVY) * W / H, tan(FOVY)) =
                                  (pixelLength.x * W / 2, pixelLength.y * H / 2) makes the reprojection exact for any field
@@ -153,6 +166,22 @@ int svgf_params_default(SvgfParams *p);
  * device `device` and zero the history (src/denoise.cu:31-61).  *out receives the handle. */
 int svgf_create(int device, int width, int height, svgf_ctx **out);
 
+/* svgf_create with flags (ABI 0.9).  SVGF_CREATE_PIPELINED: also create the frame pipeline's resources now (see
+ * SvgfParams::inputs_ready) — second colour-plane set, two internal streams, events, the hardware-queue probe — so that no frame of
+ * the sequence ever allocates or synchronises.  Unknown flag bits are SVGF_ERR_INVALID_ARG. */
+#define SVGF_CREATE_PIPELINED 1u
+int svgf_create_ex(int device, int width, int height, unsigned flags, svgf_ctx **out);
+
+/* The same resources for an existing context, between frames (allocates, synchronises the device; not under stream capture).
+ * Idempotent.  Returns SVGF_OK also when the probe refuses the promise: ask svgf_pipeline_status. */
+int svgf_enable_pipeline(svgf_ctx *ctx);
+
+/* 0: the context has no pipeline resources (inputs_ready is ignored); 1: it has, and promised frames run on the internal streams;
+ * 2: it has, but the two internal streams share a hardware queue of the HIP runtime — the promise (inputs_ready = 1) is refused and
+ *    such frames run ordered on the caller's stream (inputs_ready = 2, the caller's own two streams, still works);
+ *    svgf_last_error(ctx) holds the explanation right after svgf_create_ex / svgf_enable_pipeline. */
+int svgf_pipeline_status(const svgf_ctx *ctx);
+
 /* denoiseFree equivalent (src/denoise.cu:63-74).  NULL is accepted. */
 int svgf_destroy(svgf_ctx *ctx);
 
@@ -180,15 +209,16 @@ int svgf_sync(svgf_ctx *ctx);
 
 /* Stream-scoped completion (ABI 0.7): block until what has been enqueued on `stream` — the stream the frames were given to
  * svgf_denoise with — has finished, and nothing else: a renderer with several streams does not stall the others.
- * svgf_denoise itself never synchronises, allocates or touches another stream, so a frame may be captured into a hipGraph
- * (hipStreamBeginCapture .. svgf_denoise .. hipStreamEndCapture) and replayed: the launches are recorded with the plane roles of
- * the captured call, so replay a graph of TWO consecutive frames (or any even number) to keep the context's rotation consistent
- * (tests/test_stream_gpu.py). */
+ * svgf_denoise itself never synchronises and never allocates (the frame pipeline's resources are created by svgf_create_ex /
+ * svgf_enable_pipeline, ABI 0.9); frames without the inputs_ready promise touch no stream but `stream`, so such a frame may be captured
+ * into a hipGraph (hipStreamBeginCapture .. svgf_denoise .. hipStreamEndCapture) and replayed: the launches are recorded with the plane
+ * roles of the captured call, so replay a graph of TWO consecutive frames (or any even number) to keep the context's rotation
+ * consistent (tests/test_stream_gpu.py).  Promised frames (inputs_ready = 1 on a pipelined context) run on the context's internal
+ * streams and `stream` waits for their end. */
 int svgf_sync_stream(svgf_ctx *ctx, void *stream);
 
-/* 1 once a frame with SvgfParams::inputs_ready has switched the context to the frame pipeline (second plane set and internal
- * streams exist; ABI 0.8), else 0.  The promise is only taken up by frames with a temporal pass and a cascade of two or more
- * levels: a context that never sees one stays as it was. */
+/* 1 while the context's frames alternate between its two plane sets (the frame pipeline is in use: resources created and either the
+ * probe accepted the promise or a frame has asked for inputs_ready = 2), else 0. */
 int svgf_is_pipelined(const svgf_ctx *ctx);
 
 /* 0 for this (product) build; 1 for the experiments build of the same sources, which additionally accepts kernel_variant 5 / 6

@@ -4,6 +4,10 @@ import sys
 import numpy as np
 import pytest
 
+# The frame-pipeline tests want the context's two internal streams on hardware queues of their own (the library probes this and
+# refuses the promise otherwise, include/svgf.h): the HIP runtime reads the limit once, when it starts — before torch is imported.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
@@ -41,15 +45,16 @@ def denoiser_for(pkg, W, H, variant=0, device=0):
 
 
 @pytest.fixture
-def experiments_lib(pkg, monkeypatch):
+def experiments_lib(pkg):
     """Tests of parked experiments: every context / producer call of the test goes to libsvgf_hip_exp.so, with an empty tuning table
     before and after."""
     if not os.path.exists(pkg.binding.LIB_EXP_PATH):
         pytest.skip("libsvgf_hip_exp.so not built (python -c 'import __graft_entry__ as g; g.build()')")
-    monkeypatch.setenv("SVGF_USE_EXPERIMENTS_LIB", "1")
+    pkg.binding.use_experiments_library(True)
     pkg.binding.exp_clear()
     yield pkg.binding
     pkg.binding.exp_clear()
+    pkg.binding.use_experiments_library(False)
 
 
 def relerr(a, b):

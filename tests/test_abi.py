@@ -40,7 +40,7 @@ def test_params_default_matches_reference_ui_defaults(pkg):
     q = pkg.reference_defaults()        # reference src/main.cpp:49-62
     for name, _ in pkg.SvgfParams._fields_[:15]:
         assert getattr(p, name) == pytest.approx(getattr(q, name)), name
-    assert lib.svgf_version() == (0 << 16) | 8
+    assert lib.svgf_version() == (0 << 16) | 9
 
 
 def test_params_size_is_exported_and_checked(pkg):
@@ -57,6 +57,8 @@ def test_error_paths_without_gpu(pkg):
     h = ctypes.c_void_p()
     assert lib.svgf_create(0, 0, 10, ctypes.byref(h)) == -1            # SVGF_ERR_INVALID_ARG
     assert lib.svgf_create(0, 16, 16, None) == -1
+    assert lib.svgf_create_ex(0, 16, 16, 0x80, ctypes.byref(h)) == -1  # unknown flag bits
+    assert lib.svgf_enable_pipeline(None) == -1 and lib.svgf_pipeline_status(None) == 0
     assert lib.svgf_destroy(None) == 0                                 # denoiseFree on NULL is harmless
     assert lib.svgf_reset(None) == -1
     if not torch.cuda.is_available():

@@ -100,7 +100,7 @@ def test_bench_distributed_branch_runs_with_one_rank_on_rccl():
     env = dict(os.environ, SVGF_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1")
     env.pop("MASTER_PORT", None)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "5", "--warmup", "2", "--no-cpu-baseline",
-                        "--min-warmup-seconds", "0.1"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900, env=env)
+                        "--min-warmup-seconds", "0.1", "--cadence-frames", "16"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900, env=env)
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert line["metric"].startswith("SVGF Mpixels/s (full pipeline) at 1080p") and line["unit"] == "Mpixels/s"
@@ -112,10 +112,22 @@ def test_bench_distributed_branch_runs_with_one_rank_on_rccl():
     vv = line["roofline"]["valu_view"]
     assert vv["simd_instruction_active_pmc"] is None or 0.5 < vv["simd_instruction_active_pmc"] <= 1.01      # a PMC record or nothing: never a literal
     assert "formula" in vv["fp32_tflops_isolated_is"] and "formula" in line["roofline"]["transcendental_gops_isolated_is"]
-    # the frame pipeline is the default of the benchmark; the line carries the ordered figure of the same process beside it, and the
-    # kernels' own durations (ordered frames) beside the durations of the timed region (two frames' kernels sharing the GPU)
-    assert line["frame_pipeline"] is True and line["ordered"]["ms_per_step"] > 0
-    assert line["roofline"]["kernels_in_flight_mean"] > 1.0 and line["roofline"]["isolated"]["frac"] > line["roofline"]["frac"]
+    # the benchmark creates its context pipelined and decides by a trial (regions of --steps frames, medians, >= 3 %) which way the timed
+    # steps run; the line carries the trial, the other leg from an identical region, and what the library's queue probe said
+    tr = line["frame_pipeline_trial"]
+    assert line["frame_pipeline_status"] == 1 and tr and len(tr["pipelined_ms"]) == len(tr["ordered_ms"]) >= 3
+    assert line["frame_pipeline"] == (tr["pipelined_median_ms"] <= 0.97 * tr["ordered_median_ms"])
+    other = line["ordered"] if line["frame_pipeline"] else line["pipelined"]
+    assert other["ms_per_step"] > 0 and line["first_frame_ms"] < 50
+    # roofline = the dominant kernel's OWN figure (ordered frames, one kernel at a time): frac x peak x duration = the algorithmic bytes
+    rf = line["roofline"]
+    assert abs(rf["frac"] * rf["peak"] * 1e9 * rf["mean_launch_us"] * 1e-6 - 56.0 * 1920 * 1080) <= 0.01 * 56.0 * 1920 * 1080
+    assert rf["timed_region"]["mean_launch_us"] >= 0.9 * rf["mean_launch_us"] and rf["timed_region"]["launches_timed"] >= 5
+    if line["frame_pipeline"]:
+        assert rf["timed_region"]["kernels_in_flight_mean"] > 1.0 and rf["timed_region"]["frac"] < rf["frac"]
+    # the state a renderer lives in: one frame per 1/60 s, GPU idle in between
+    cd = line["cadence"]
+    assert cd["hz"] == 60.0 and cd["ms_per_step"] > 0.9 * line["ms_per_step"] and cd["frames"] >= 8
 
 
 @pytest.mark.gpu

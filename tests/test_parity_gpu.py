@@ -350,8 +350,8 @@ def test_back_to_back_asynchronous_frames_equal_synchronised_frames(pkg, history
     """Eight frames enqueued back to back on one stream with no host synchronisation in between must give exactly what the
     same frames give when the host waits after every call, for every position of the history level: the plane rotation
     (three colour planes; the fused first level reads the OLD colour history while it writes the new one) must not let a
-    frame overwrite what a kernel still in flight reads.  Also: SvgfParams::inputs_ready (the cross-frame overlap of rounds
-    1-3) is accepted and changes nothing."""
+    frame overwrite what a kernel still in flight reads.  Also: the same frames promised (SvgfParams::inputs_ready = 1) on a
+    context created pipelined: bit-identical."""
     import torch
     W, H, N = 1920, 1080, 8
     frames = [pkg.synth.render_frame(W, H, f, seed=37, moving=True) for f in range(4)]
@@ -361,7 +361,7 @@ def test_back_to_back_asynchronous_frames_equal_synchronised_frames(pkg, history
     for mode in ("sync", "async", "async+inputs_ready"):
         p = pkg.reference_defaults().set(temporal_enable=1, spatial_enable=1, history_level=history_level,
                                          inputs_ready=1 if mode.endswith("ready") else 0)
-        d = pkg.Denoiser(W, H, 0)
+        d = pkg.Denoiser(W, H, 0, pipelined=mode.endswith("ready"))
         outs = [torch.empty((H, W, 3), dtype=torch.float32, device="cuda") for _ in range(N)]
         stream = torch.cuda.current_stream()
         torch.cuda.synchronize()

@@ -1,4 +1,4 @@
-"""The frame pipeline (SvgfParams::inputs_ready, ABI 0.8): consecutive frames of ONE sequence on two internal streams.
+"""The frame pipeline (SvgfParams::inputs_ready, ABI 0.8; explicit resources since 0.9): consecutive frames of ONE sequence on two internal streams.
 
 A frame's temporal pass needs of the previous frame only what exists once the level that feeds the colour history has run (level 1 with
 the reference's defaults, src/denoise.cu:391); levels 2-5 of frame n and the temporal pass + level 1 of frame n+1 are independent.  A
@@ -28,7 +28,8 @@ def _inputs(pkg, W, H, n, seed, moving=True):
 def _run(pkg, W, H, fr, tin, tg, plist, stream=None, reset_at=()):
     """One context, one frame per entry of plist (SvgfParams), every frame its own output buffer."""
     import torch
-    d = pkg.Denoiser(W, H, 0)
+    d = pkg.Denoiser(W, H, 0, pipelined=any(p.inputs_ready for p in plist))      # (only a context created pipelined looks at inputs_ready)
+    assert not any(p.inputs_ready for p in plist) or d.pipeline_status() == 1, d.last_error()
     outs = [torch.empty((H, W, 3), dtype=torch.float32, device="cuda") for _ in plist]
     s = stream or torch.cuda.current_stream()
     for k, p in enumerate(plist):
@@ -97,7 +98,9 @@ def test_pipelined_1080p_sequence_matches_the_oracle(pkg, orc):
 def test_a_pipelined_context_joins_a_stream_capture(pkg):
     """Under hipStreamBeginCapture nothing can be promised: the frames of a pipelined context are recorded on the capturing stream
     itself, so the whole frame is part of the graph.  Two frames per graph (plane
-    parities), replayed three times, against the same eight frames run eagerly."""
+    parities), replayed three times, against the same eight frames run eagerly.  Then PROMISED eager frames again, enqueued right
+    behind the last replay without any host synchronisation: a context that has been captured orders them behind the caller's stream
+    (the replay uses the same planes and is visible only there), so the sequence goes on bit-identically."""
     import torch
     for ln in open("/proc/self/maps"):
         if "libamdhip64" in ln:
@@ -106,12 +109,13 @@ def test_a_pipelined_context_joins_a_stream_capture(pkg):
     W, H = 640, 360
     fr, tin, tg = _inputs(pkg, W, H, 2, seed=9, moving=False)
     p = pkg.reference_defaults().set(temporal_enable=1, spatial_enable=1, atrous_nlevel=5, history_level=1, inputs_ready=1)
-    want = _run(pkg, W, H, fr, tin, tg, [p] * 8)[0]
-    d = pkg.Denoiser(W, H, 0)
+    want = _run(pkg, W, H, fr, tin, tg, [p] * 12)[0]
+    d = pkg.Denoiser(W, H, 0, pipelined=True)
     s = torch.cuda.Stream()
     outs = [torch.empty((H, W, 3), dtype=torch.float32, device="cuda") for _ in range(2)]
+    tail = [torch.empty((H, W, 3), dtype=torch.float32, device="cuda") for _ in range(4)]
     got = []
-    for k in range(2):          # eager: the context becomes pipelined here (allocation + device synchronisation, once)
+    for k in range(2):          # eager, promised: on the context's internal streams
         d.denoise(outs[k], tin[k], tg[k], fr[k][2], p, stream=s)
     s.synchronize()
     got += [o.cpu().numpy() for o in outs]
@@ -123,11 +127,19 @@ def test_a_pipelined_context_joins_a_stream_capture(pkg):
     assert hip.hipGraphInstantiate(ctypes.byref(gexec), graph, None, None, 0) == 0
     for rep in range(3):
         assert hip.hipGraphLaunch(gexec, ctypes.c_void_p(s.cuda_stream)) == 0
-        s.synchronize()
-        got += [o.cpu().numpy() for o in outs]
+        if rep < 2:
+            s.synchronize()
+            got += [o.cpu().numpy() for o in outs]
+    # behind the LAST replay, not waited for: copies of its two outputs, then four promised eager frames
+    with torch.cuda.stream(s):
+        last = [o.clone() for o in outs]
+    for k in range(4):
+        d.denoise(tail[k], tin[k & 1], tg[k & 1], fr[k & 1][2], p, stream=s)
+    s.synchronize()
+    got += [o.cpu().numpy() for o in last] + [o.cpu().numpy() for o in tail]
     hip.hipGraphExecDestroy(gexec); hip.hipGraphDestroy(graph)
     d.free()
-    for k in range(8):
+    for k in range(12):
         assert np.array_equal(want[k], got[k]), f"frame {k}"
 
 
@@ -157,7 +169,7 @@ def test_profile_entries_of_pipelined_frames(pkg):
     fr, tin, tg = _inputs(pkg, W, H, 2, seed=3, moving=False)
     import torch
     p = pkg.reference_defaults().set(temporal_enable=1, spatial_enable=1, atrous_nlevel=5, history_level=1, inputs_ready=1)
-    d = pkg.Denoiser(W, H, 0)
+    d = pkg.Denoiser(W, H, 0, pipelined=True)
     d.profile_enable(6)
     outs = [torch.empty((H, W, 3), dtype=torch.float32, device="cuda") for _ in range(2)]
     for k in range(6):
@@ -194,7 +206,7 @@ def test_two_alternating_streams_without_the_promise(pkg):
     p0 = pkg.reference_defaults().set(temporal_enable=1, spatial_enable=1, atrous_nlevel=5, history_level=1)
     want = _run(pkg, W, H, fr, tin, tg, [p0] * N)[0]
     p = pkg.SvgfParams.from_buffer_copy(p0).set(inputs_ready=2)
-    d = pkg.Denoiser(W, H, 0)
+    d = pkg.Denoiser(W, H, 0, pipelined=True)
     st = [torch.cuda.Stream(), torch.cuda.Stream()]
     cin = [torch.empty_like(tin[0]) for _ in range(2)]
     cg = [torch.empty_like(tg[0]) for _ in range(2)]
@@ -227,7 +239,7 @@ def test_readers_of_the_output_enqueued_behind_earlier_calls_are_safe(pkg):
     p0 = pkg.reference_defaults().set(temporal_enable=1, spatial_enable=1, atrous_nlevel=5, history_level=1)
     want = _run(pkg, W, H, fr, tin, tg, [p0] * N)[0]
     p = pkg.SvgfParams.from_buffer_copy(p0).set(inputs_ready=1)
-    d = pkg.Denoiser(W, H, 0)
+    d = pkg.Denoiser(W, H, 0, pipelined=True)
     s = torch.cuda.Stream()
     out = torch.empty((H, W, 3), dtype=torch.float32, device="cuda")
     keep = [torch.empty((H, W, 3), dtype=torch.float32, device="cuda") for _ in range(N)]
@@ -244,3 +256,48 @@ def test_readers_of_the_output_enqueued_behind_earlier_calls_are_safe(pkg):
     d.free()
     for k in range(N):
         assert np.array_equal(want[k], got[k]), f"frame {k}"
+
+
+def test_promise_is_refused_when_the_internal_streams_share_a_hardware_queue(pkg):
+    """GPU_MAX_HW_QUEUES=1 (read by the HIP runtime at start-up, hence a subprocess): the probe of svgf_create_ex finds the two internal
+    streams serialised, svgf_pipeline_status says 2, svgf_last_error explains, and promised frames then run as ordinary ordered frames
+    — so they are not slower than ordered frames (on one queue the pipelined form used to lose 8-10 %), and bit-identical."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    code = r"""
+import sys, time, json
+sys.path.insert(0, %r)
+import numpy as np, torch
+import __graft_entry__ as ge
+pkg = ge.load_package()
+W, H = 1920, 1080
+fr = [pkg.synth.render_frame(W, H, f, seed=3, moving=False) for f in range(2)]
+tin = [torch.from_numpy(f[0]).cuda() for f in fr]; tg = [torch.from_numpy(f[1].view(np.uint8).reshape(-1)).cuda() for f in fr]
+outs = [torch.empty((H, W, 3), dtype=torch.float32, device='cuda') for _ in range(2)]
+base = pkg.reference_defaults().set(temporal_enable=1, spatial_enable=1, atrous_nlevel=5, history_level=1)
+res = {}
+for name, piped in (('ordered', False), ('promised', True)):
+    d = pkg.Denoiser(W, H, 0, pipelined=piped)
+    p = pkg.SvgfParams.from_buffer_copy(base).set(inputs_ready=1 if piped else 0)
+    res[name + '_status'] = d.pipeline_status(); res[name + '_err'] = d.last_error()
+    def burst(n):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for k in range(n): d.denoise(outs[k & 1], tin[k & 1], tg[k & 1], fr[k & 1][2], p)
+        torch.cuda.synchronize(); return (time.perf_counter() - t0) / n * 1e3
+    burst(600)
+    res[name] = float(np.median([burst(40) for _ in range(5)]))
+    res[name + '_sum'] = float(outs[1].double().sum().item()); res[name + '_piped'] = d.is_pipelined()
+    d.free()
+print('RESULT ' + json.dumps(res))
+""" % ROOT
+    env = dict(os.environ, GPU_MAX_HW_QUEUES="1")
+    r = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    import json
+    res = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("RESULT ")][-1][7:])
+    print(res)
+    assert res["ordered_status"] == 0 and res["promised_status"] == 2 and "hardware queue" in res["promised_err"] and not res["promised_piped"]
+    assert res["promised"] <= 1.02 * res["ordered"], res
+    assert res["promised_sum"] == res["ordered_sum"]
