@@ -161,3 +161,39 @@ def test_bench_launcher_two_ranks_sharing_one_gpu():
     assert [r_["rank"] for r_ in pr] == [0, 1] and all(r_["device"] == 0 for r_ in pr)
     assert all(0 < r_["ms_per_step"] <= line["ms_per_step"] * 1.001 for r_ in pr)
     assert pr[0]["cpus"] and pr[1]["cpus"] and not (set(pr[0]["cpus"]) & set(pr[1]["cpus"])) or len(os.sched_getaffinity(0)) < 2
+
+
+@pytest.mark.gpu
+def test_bench_launcher_eight_ranks_sharing_one_gpu_on_configs4():
+    """BASELINE configs[4]'s command, `python bench.py --gpus 8 --config 4k-room`, as far as ONE GPU can take it (SVGF_BENCH_SHARE_DEVICE=1):
+    the launcher spawns eight ranks, they rendezvous (gloo here; RCCL with a GPU each), every rank pins itself to its own slice of the
+    CPUs the container may use, ray-casts room.txt at 3840x2160 with the device producer, creates its own 4K context (eight of them fit
+    one device with room to spare: 8 x ~4 GB of 288), and ONE JSON line with eight per_rank entries comes out.  No 1 -> 8 scaling
+    number is claimed anywhere: no run of this repository has had two GPUs."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = dict(os.environ, SVGF_BENCH_SHARE_DEVICE="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--config", "4k-room", "--steps", "3", "--warmup", "1",
+                        "--min-warmup-seconds", "0.05", "--latency-calls", "50", "--trial-reps", "1"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=1500, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, f"{len(lines)} JSON lines from an 8-rank run"
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 8 and line["steps"] == 3 and line["scaling"] == "weak" and line["config"]["name"] == "4k-room"
+    assert line["config"]["width"] == 3840 and line["config"]["parallelism"].startswith("replicas8")
+    px = 3840 * 2160
+    assert abs(line["value"] * 1e6 * line["ms_per_step"] * 1e-3 - 8 * px) <= 0.01 * 8 * px      # all ranks' pixels over the slowest rank's time
+    pr = line["per_rank"]
+    assert [e["rank"] for e in pr] == list(range(8)) and all(e["device"] == 0 for e in pr)
+    assert all(0 < e["ms_per_step"] <= line["ms_per_step"] * 1.001 for e in pr)
+    ncpu = len(os.sched_getaffinity(0))
+    if ncpu >= 8:
+        sets = [set(e["cpus"]) for e in pr]
+        assert all(sets) and all(not (sets[i] & sets[j]) for i in range(8) for j in range(i)), sets
+    assert "cpu_baseline" not in line and line["cadence"] is None
