@@ -217,8 +217,14 @@ def main():
     # profiles/r05_exp_pipeline.log).  Read by the runtime at initialisation, so it is set before torch is imported; a value from
     # the environment wins.
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
-    os.environ.setdefault("OMP_PLACES", "cores")
-    os.environ.setdefault("OMP_PROC_BIND", "spread")     # one thread per core, spread over the CCDs: the oracle lives in L3 (close: 5.2, spread: 8.7 Mpix/s at 16 threads)
+    cpus_of_rank = None
+    if a.gpus > 1 and "WORLD_SIZE" in os.environ:
+        # N > 1: this rank's slice of the CPUs, taken BEFORE any OpenMP runtime starts (torch's binds the main thread to one core when
+        # OMP_PROC_BIND is set, and an affinity mask read after that is that one core: every rank would pin itself to the same one)
+        cpus_of_rank = pkg_cpu_slice(int(os.environ.get("RANK", "0")), int(os.environ["WORLD_SIZE"]))
+    elif a.gpus == 1:
+        os.environ.setdefault("OMP_PLACES", "cores")
+        os.environ.setdefault("OMP_PROC_BIND", "spread")     # the CPU-baseline leg (N = 1 only): one thread per core, spread over the CCDs: the oracle lives in L3 (close: 5.2, spread: 8.7 Mpix/s at 16 threads)
 
     import torch
     # SVGF_BENCH_SHARE_DEVICE=1 (tests only): every rank uses device 0 and the ranks rendezvous over gloo — N processes with N
@@ -262,7 +268,6 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
-    cpus_of_rank = pkg_cpu_slice(rank, world)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
@@ -282,7 +287,7 @@ def main():
     params.set(kernel_variant=a.kernel_variant)
     if a.config == "config1":   # BASELINE configs[0]: the reference's own CPU-runnable case
         params.set(temporal_enable=0, atrous_nlevel=1)
-    pipeline = not (a.no_pipeline or a.no_overlap or a.planar_inputs)      # (the planar path orders its frames: the library ignores the promise there)
+    pipeline = not (a.no_pipeline or a.no_overlap)      # (--planar-inputs: the planes of both parities are filled once, before the timed region: the promise holds)
     params.set(inputs_ready=1 if pipeline else 0)
 
     # every rank owns one independent sequence (its own seed); 4 distinct noisy frames, static camera, resident in HBM
@@ -343,17 +348,18 @@ def main():
     if a.planar_inputs:
         if moving or a.host_inputs:
             raise SystemExit("--planar-inputs: static-camera configs with the device producer only")
-        for _ in range(2):      # both plane sets (they alternate with the history) get the static scene's G-buffer
-            pkg.binding.synth_render_planar(d_in[0], den.planar_gbuffer(), W, H, cam_dicts[0], 0, seed=1000 + seq, device=local_rank)
-            den.denoise_planar(out, d_in[0], cams[0], params, stream=stream)
-        torch.cuda.synchronize(dev)
+        for dd, pr in {id(den): (den, params), id(den_o): (den_o, op)}.values():
+            for _ in range(2):      # both plane sets (they alternate with the history) get the static scene's G-buffer
+                pkg.binding.synth_render_planar(d_in[0], dd.planar_gbuffer(), W, H, cam_dicts[0], 0, seed=1000 + seq, device=local_rank)
+                dd.denoise_planar(out, d_in[0], cams[0], pr, stream=stream)
+            torch.cuda.synchronize(dev)
 
     cur = {"den": den, "params": params}      # what the timed steps run on (the pipeline trial below may swap in the ordered twin)
 
     def step(i):
         k = i % nsrc
         if a.planar_inputs:
-            cur["den"].denoise_planar(out, d_in[k], cams[k], cur["params"], stream=stream)
+            cur["den"].denoise_planar(outs[i & 1], d_in[k], cams[k], cur["params"], stream=stream)
         else:
             cur["den"].denoise(outs[i & 1], d_in[k], d_g[k], cams[k], cur["params"], stream=stream)
         return W * H
@@ -361,7 +367,7 @@ def main():
     def step_ordered(i):
         k = i % nsrc
         if a.planar_inputs:
-            den_o.denoise_planar(out, d_in[k], cams[k], op, stream=stream)
+            den_o.denoise_planar(outs[i & 1], d_in[k], cams[k], op, stream=stream)
         else:
             den_o.denoise(outs[i & 1], d_in[k], d_g[k], cams[k], op, stream=stream)
 
@@ -411,7 +417,10 @@ def main():
 
     def step_pipe(i):
         k = i % nsrc
-        den.denoise(outs[i & 1], d_in[k], d_g[k], cams[k], params, stream=stream)
+        if a.planar_inputs:
+            den.denoise_planar(outs[i & 1], d_in[k], cams[k], params, stream=stream)
+        else:
+            den.denoise(outs[i & 1], d_in[k], d_g[k], cams[k], params, stream=stream)
 
     def settle(fn, seconds):
         t, k = time.perf_counter(), 0
@@ -488,6 +497,26 @@ def main():
         lat.append(time.perf_counter() - t0)
     t_lat1 = time.perf_counter()
     lat_ms = np.asarray(lat) * 1e3
+    # What the reference's caller does next (src/pathtrace.cu:446-449): the side-by-side pack kernel, then a blocking copy.  With the shim's
+    # trailing device sync (src/denoise.cu:401) the pack kernel is launched after a host round trip; without it
+    # (-DSVGF_COMPAT_NO_TRAILING_SYNC in denoise_compat.cpp) it is already queued when the last level ends.  Same results either way.
+    caller_ms = None
+    if world == 1 and not a.planar_inputs:
+        pbo_l = torch.empty((H, 2 * W, 4), dtype=torch.uint8, device=dev)
+        legs = {"denoise_sync_pack_sync": [], "denoise_pack_sync": []}
+        for i in range(2 * max(50, a.latency_calls) + 20):
+            which = "denoise_sync_pack_sync" if i & 1 else "denoise_pack_sync"
+            t0 = time.perf_counter()
+            step_ordered(i)
+            if i & 1:
+                den_o.sync()
+            pkg.binding.display_pack(pbo_l, d_in[i % nsrc], outs[i & 1], W, H, device=local_rank, stream=stream)
+            den_o.sync()
+            if i >= 20:
+                legs[which].append((time.perf_counter() - t0) * 1e3)
+        caller_ms = {k: round(float(np.median(v)), 5) for k, v in legs.items()}
+        caller_ms["what"] = ("median wall time of svgf_denoise [+ svgf_sync] + svgf_display_pack + sync per frame, the two orders alternating: the reference's "
+                             "(device sync inside denoise(), src/denoise.cu:401) and the shim built with -DSVGF_COMPAT_NO_TRAILING_SYNC")
     if not (np.isfinite(outs[0].sum().item()) and np.isfinite(outs[1].sum().item())):
         raise SystemExit("bench: non-finite output")
 
@@ -520,15 +549,21 @@ def main():
     iso_params.set(kernel_variant=a.kernel_variant)
     if a.config == "config1":
         iso_params.set(temporal_enable=0, atrous_nlevel=1)
+    def iso_step(i):
+        if a.planar_inputs:
+            den_o.denoise_planar(out, d_in[i % nsrc], cams[i % nsrc], iso_params, stream=stream)
+        else:
+            den_o.denoise(out, d_in[i % nsrc], d_g[i % nsrc], cams[i % nsrc], iso_params, stream=stream)
+
     den_o.profile_stride(1)
     den_o.profile_enable(16)
     for i in range(256):      # back into the sustained clock state (the latency loop above idles the GPU between calls: DESIGN.md 6.2)
-        den_o.denoise(out, d_in[i % nsrc], d_g[i % nsrc], cams[i % nsrc], iso_params, stream=stream)
+        iso_step(i)
     torch.cuda.synchronize(dev)
     den_o.profile_enable(16)    # same slot count: counters restart, no event is re-created, no idle time
     t_iso0 = time.perf_counter()
     for i in range(16):
-        den_o.denoise(out, d_in[i % nsrc], d_g[i % nsrc], cams[i % nsrc], iso_params, stream=stream)
+        iso_step(i)
     torch.cuda.synchronize(dev)
     t_iso1 = time.perf_counter()
     iso_atrous_ms = [ms for s in range(den_o.profile_frames()) for kind, ms in den_o.profile_read(s)
@@ -641,6 +676,7 @@ def main():
                         "mpixels_per_s": round(W * H / (float(np.median(lat_ms)) * 1e-3) / 1e6, 1),
                         "what": "wall time of svgf_denoise + svgf_sync per call (rank 0), what the reference's synchronous denoise() gives its caller"
                                 + ("; measured on a context of its own with inputs_ready = 0: a caller that waits after every call promises nothing" if pipeline else "")},
+            "latency_caller_ms": caller_ms,
             "idle_before_timed_region_ms": round((t_region0 - t_warm_end) * 1e3, 3),      # GPU idle between warm-up and timed steps
             "telemetry": {"timed_region": tm_all.summary(t_region0, t_region1), "latency_calls": tm_all.summary(t_lat0, t_lat1),
                           "isolated_16_frames": tm_all.summary(t_iso0, t_iso1)},

@@ -32,7 +32,7 @@ EXPORTS = ["svgf_version", "svgf_params_default", "svgf_create", "svgf_destroy",
            "svgf_synth_camera", "svgf_synth_render", "svgf_scene_render", "svgf_scene_render_mesh", "svgf_display_pack", "svgf_save_png",
            "svgf_planar_gbuffer", "svgf_denoise_planar", "svgf_synth_render_planar", "svgf_params_sizeof", "svgf_scene_render_mesh_planar",
            "svgf_sync_stream", "svgf_build_has_experiments", "svgf_is_pipelined", "svgf_create_ex", "svgf_enable_pipeline",
-           "svgf_pipeline_status"]
+           "svgf_pipeline_status", "svgf_planar_gbuffer_stream"]
 CREATE_PIPELINED = 1
 
 
@@ -174,6 +174,7 @@ def load_library(path: str | None = None, experiments: bool = False):
     lib.svgf_scene_render_mesh_planar.argtypes = [ip, vp, C.POINTER(SvgfPlanarGBuffer), ip, ip, C.POINTER(SvgfCamera), C.POINTER(SvgfSynthParams), vp, ip,
                                                   vp, vp, vp, vp, ip, vp, vp, vp, ip, C.POINTER(C.c_float), vp]
     lib.svgf_planar_gbuffer.argtypes = [vp, C.POINTER(SvgfPlanarGBuffer)]
+    lib.svgf_planar_gbuffer_stream.argtypes = [vp, C.POINTER(SvgfPlanarGBuffer), vp]
     lib.svgf_denoise_planar.argtypes = [vp, vp, vp, C.POINTER(SvgfCamera), C.POINTER(SvgfParams), vp]
     lib.svgf_synth_render_planar.argtypes = [ip, vp, C.POINTER(SvgfPlanarGBuffer), ip, ip, C.POINTER(SvgfCamera), C.POINTER(SvgfSynthParams), vp]
     lib.svgf_params_sizeof.restype = ip
@@ -245,10 +246,16 @@ class Denoiser:
         self._check(self.lib.svgf_denoise(self.h, _ptr(out), _ptr(inp), _ptr(gbuffer), C.byref(cam), C.byref(p), s),
                     "svgf_denoise")
 
-    def planar_gbuffer(self) -> SvgfPlanarGBuffer:
-        """The planes the NEXT denoise_planar() call consumes: a producer fills them in place."""
+    def planar_gbuffer(self, stream=None) -> SvgfPlanarGBuffer:
+        """The planes the NEXT denoise_planar() call consumes: a producer fills them in place.
+        stream given: svgf_planar_gbuffer_stream — on a pipelined context the producer's stream waits for exactly the frames that
+        still read those planes instead of the host waiting for the device."""
         g = SvgfPlanarGBuffer()
-        self._check(self.lib.svgf_planar_gbuffer(self.h, C.byref(g)), "svgf_planar_gbuffer")
+        if stream is None:
+            self._check(self.lib.svgf_planar_gbuffer(self.h, C.byref(g)), "svgf_planar_gbuffer")
+        else:
+            s = stream if isinstance(stream, int) else stream.cuda_stream
+            self._check(self.lib.svgf_planar_gbuffer_stream(self.h, C.byref(g), s), "svgf_planar_gbuffer_stream")
         return g
 
     def denoise_planar(self, out, inp, camera, params: SvgfParams | None = None, stream=None):

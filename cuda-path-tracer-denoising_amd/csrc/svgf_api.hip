@@ -49,6 +49,9 @@ struct svgf_ctx {
     int ever_captured;     // a frame of this context has been recorded into a graph: promised frames order themselves behind `stream`
     hipStream_t pipe[2];
     hipEvent_t ev_hist[2], ev_done[2], ev_in;
+    hipEvent_t ev_tdone[2];   // planar frames: behind the temporal pass (the last reader of the PREVIOUS frame's G-buffer planes, which the next producer overwrites)
+    int ev_tdone_valid[2];
+    int last_modulated;       // the last frame's last level read the (single) albedo plane
     int ev_hist_valid[2];
     unsigned long long ev_hist_cap[2];      // the stream-capture id ev_hist[q] was last recorded under (0: eagerly)
     int ev_done_valid[2];
@@ -217,6 +220,7 @@ static void free_all(svgf_ctx *c)
         if (c->pipe[q]) (void)hipStreamDestroy(c->pipe[q]);
         if (c->ev_hist[q]) (void)hipEventDestroy(c->ev_hist[q]);
         if (c->ev_done[q]) (void)hipEventDestroy(c->ev_done[q]);
+        if (c->ev_tdone[q]) (void)hipEventDestroy(c->ev_tdone[q]);
     }
     if (c->ev_in) (void)hipEventDestroy(c->ev_in);
     for (int k = 0; k < 2; k++) if (c->tp[k]) (void)hipFree(c->tp[k]);
@@ -238,6 +242,7 @@ static int zero_state(svgf_ctx *c)
     c->vp_valid = 0;
     c->pipe_frames = 0; c->ev_hist_valid[0] = c->ev_hist_valid[1] = 0; c->ev_hist_cap[0] = c->ev_hist_cap[1] = 0;      // (a pipelined context stays pipelined)
     c->ev_done_valid[0] = c->ev_done_valid[1] = 0; c->ev_done_cap[0] = c->ev_done_cap[1] = 0;
+    c->ev_tdone_valid[0] = c->ev_tdone_valid[1] = 0;
     for (int k = 0; k < 2; k++) {
         HIPC(c, hipMemset(c->nrm[k], 0, c->n * 3 * sizeof(float)));
         HIPC(c, hipMemset(c->gid[k], 0, c->n * sizeof(int)));
@@ -590,6 +595,7 @@ static int enable_pipeline(svgf_ctx *c)
         if (!c->pipe[q]) HIPC(c, hipStreamCreateWithFlags(&c->pipe[q], hipStreamNonBlocking));
         if (!c->ev_hist[q]) HIPC(c, hipEventCreateWithFlags(&c->ev_hist[q], hipEventDisableTiming));
         if (!c->ev_done[q]) HIPC(c, hipEventCreateWithFlags(&c->ev_done[q], hipEventDisableTiming));
+        if (!c->ev_tdone[q]) HIPC(c, hipEventCreateWithFlags(&c->ev_tdone[q], hipEventDisableTiming));
     }
     if (!c->ev_in) HIPC(c, hipEventCreateWithFlags(&c->ev_in, hipEventDisableTiming));
     bool overlap = true;
@@ -698,7 +704,10 @@ static int denoise_frame(svgf_ctx *c, void *out_rgb_dev, const void *in_rgb_dev,
     // inputs_ready == 2 asks for the pipeline WITHOUT the promise: the frame is ordered behind `stream` like any other work (its
     // inputs may be produced there, its output consumed there), and a caller that alternates TWO streams from frame to frame gets
     // the same overlap with nothing but stream semantics — a stream only ever waits for the frames that were given to it.
-    const bool worth = gbuffer_dev != nullptr && p->temporal_enable && p->spatial_enable && p->atrous_nlevel >= 2 &&
+    // (planar frames too, ABI 0.9: the promise then covers the context's own current-frame planes — written, complete, and not
+    // rewritten before the work of this call is done; a producer that refills them every frame takes the pointers through
+    // svgf_planar_gbuffer_stream, which orders it behind the frames that still read them)
+    const bool worth = p->temporal_enable && p->spatial_enable && p->atrous_nlevel >= 2 &&
                        p->right_view_option != 1 && p->right_view_option != 2 && p->history_level != p->atrous_nlevel;
     // Only a context whose pipeline resources exist (svgf_create_ex(SVGF_CREATE_PIPELINED) / svgf_enable_pipeline) takes either form up:
     // svgf_denoise never allocates.  The promise additionally needs the two internal streams on different hardware queues (probed when
@@ -723,6 +732,7 @@ static int denoise_frame(svgf_ctx *c, void *out_rgb_dev, const void *in_rgb_dev,
     }
     const bool piped = c->piped_mode != 0;
     if (piped && cap_id) c->ever_captured = 1;
+    if (piped) c->ev_tdone_valid[c->pipe_frames & 1] = 0;      // (re-armed below by a planar frame's temporal pass)
     const int pq = piped ? (int)(c->pipe_frames & 1) : 0;
     const int pbase = piped ? 3 * pq : 0;          // this frame's plane set
     // A promised frame runs on the context's stream of its parity.  Every other frame of a pipelined context runs on the caller's own
@@ -800,6 +810,7 @@ static int denoise_frame(svgf_ctx *c, void *out_rgb_dev, const void *in_rgb_dev,
         t.skip_split = split_fused ? 1 : 0;
         if (!fused) {
             LAUNCH(SVGF_KERNEL_TEMPORAL, launch_temporal(t, s));
+            if (piped && !g && !cap_id) { HIPC(c, hipEventRecord(c->ev_tdone[pq], s)); c->ev_tdone_valid[pq] = 1; }
             if (p->spatial_variance_frames > 0)      // f4 extension: spatial variance estimate for short histories (its own profiling slot, same kind)
                 LAUNCH(SVGF_KERNEL_TEMPORAL, launch_spatial_variance(c->cv[acc], c->mom[1 - c->cur], c->hlen[1 - c->cur], c->nrm[gnew], c->gid[gnew],
                                                                      c->W, c->H, p->spatial_variance_frames, s));
@@ -963,6 +974,7 @@ static int denoise_frame(svgf_ctx *c, void *out_rgb_dev, const void *in_rgb_dev,
         if (s != s_user) HIPC(c, hipStreamWaitEvent(s_user, c->ev_done[pq], 0));      // what the caller enqueues behind this call sees `out`
         c->pipe_frames++;
     }
+    c->last_modulated = (cascade && p->sepcolor && p->addcolor) ? 1 : 0;
     // 3) history rotation (:396-399): planes swap roles instead of being copied
     if (p->temporal_enable) c->cur = 1 - c->cur;
     c->gcur = gnew;
@@ -984,7 +996,7 @@ extern "C" int svgf_denoise(svgf_ctx *c, void *out_rgb_dev, const void *in_rgb_d
 }
 
 // ---- the planar path (the AoS -> plane repack fused into the producer) -----------------------
-extern "C" int svgf_planar_gbuffer(svgf_ctx *c, SvgfPlanarGBuffer *out)
+static int planar_gbuffer(svgf_ctx *c, SvgfPlanarGBuffer *out, bool have_stream, hipStream_t stream)
 {
     if (!c || !out) return SVGF_ERR_INVALID_ARG;
     SvgfDeviceGuard dev_guard(c->device);
@@ -996,15 +1008,30 @@ extern "C" int svgf_planar_gbuffer(svgf_ctx *c, SvgfPlanarGBuffer *out)
         HIPC(c, hipMemset(c->albedo, 0, c->n * 3 * sizeof(float)));
         HIPC(c, hipStreamSynchronize(nullptr));
     }
-    // The planes handed out were the current planes of the frame before last; the producer writes them on a stream of its own
-    // choosing.  On an ordered context that stream has waited for every frame (stream order); frames of a PIPELINED context may still be
-    // running on another stream of the caller's or on the context's own, so the hand-out waits for them — the planar path orders its
-    // frames anyway (svgf_denoise_planar never pipelines).
-    if (c->piped_mode) HIPC(c, hipDeviceSynchronize());
+    // The planes handed out were the CURRENT planes of the frame before last (its levels read them) and are the PREVIOUS planes of
+    // the last frame (its temporal pass reads them); the producer writes them on a stream of its own choosing.  On an ordered context
+    // that stream has waited for every frame (stream order).  Frames of a PIPELINED context may still be running on another stream of
+    // the caller's or on the context's own: svgf_planar_gbuffer waits for the device; svgf_planar_gbuffer_stream makes `stream` wait
+    // for exactly the two things that still read the planes — the end of the frame before last and the temporal pass of the last
+    // frame (and the last frame's end when its last level read the one albedo plane) — so that the producer of frame n+1 runs
+    // beside the levels of frame n.
+    if (c->piped_mode) {
+        if (!have_stream) HIPC(c, hipDeviceSynchronize());
+        else {
+            const int pq = (int)(c->pipe_frames & 1);      // parity of the NEXT frame = parity of the frame before last
+            if (c->ev_done_valid[pq] && !c->ev_done_cap[pq]) HIPC(c, hipStreamWaitEvent(stream, c->ev_done[pq], 0));
+            if (c->ev_tdone_valid[1 - pq]) HIPC(c, hipStreamWaitEvent(stream, c->ev_tdone[1 - pq], 0));
+            else if (c->ev_done_valid[1 - pq] && !c->ev_done_cap[1 - pq]) HIPC(c, hipStreamWaitEvent(stream, c->ev_done[1 - pq], 0));      // (the last frame was not a planar one)
+            if (c->last_modulated && c->ev_done_valid[1 - pq] && !c->ev_done_cap[1 - pq]) HIPC(c, hipStreamWaitEvent(stream, c->ev_done[1 - pq], 0));
+        }
+    }
     const int gnew = 1 - c->gcur;        // the planes the next frame's temporal / prepare pass treats as "current"
     out->normal = c->nrm[gnew]; out->position = c->pos[gnew]; out->geom_id = c->gid[gnew]; out->albedo = c->albedo;
     return SVGF_OK;
 }
+
+extern "C" int svgf_planar_gbuffer(svgf_ctx *c, SvgfPlanarGBuffer *out) { return planar_gbuffer(c, out, false, nullptr); }
+extern "C" int svgf_planar_gbuffer_stream(svgf_ctx *c, SvgfPlanarGBuffer *out, void *stream) { return planar_gbuffer(c, out, true, (hipStream_t)stream); }
 
 extern "C" int svgf_denoise_planar(svgf_ctx *c, void *out_rgb_dev, const void *in_rgb_dev, const SvgfCamera *cam, const SvgfParams *p, void *stream)
 {

@@ -123,7 +123,10 @@ typedef struct SvgfParams {
                                  frame to frame — each with its own input / output buffers — gets the same overlap from plain
                                  stream semantics, because a stream only waits for the frames that were given to it
                                  (examples/pipeline.cpp: producer + denoiser of consecutive frames overlapping, no events).
-                                 Ignored — the frame is ordered on `stream` — on the planar path and while `stream` is being
+                                 Planar frames (svgf_denoise_planar) take both forms up too (ABI 0.9): the promise then covers the
+                                 context's own current-frame planes — filled, complete, and not refilled before the work of the
+                                 call is done; a producer that refills them every frame takes the pointers through
+                                 svgf_planar_gbuffer_stream.  Ignored — the frame is ordered on `stream` — while `stream` is being
                                  captured into a graph.  Once a frame of the context HAS been captured, promised frames order
                                  themselves behind `stream` entirely (a replay of the graph on `stream` uses the same planes): mix
                                  graph replay and the promise only if that is acceptable.  One-launch frames (temporal off, one level)
@@ -304,6 +307,12 @@ typedef struct SvgfPlanarGBuffer {
     float *albedo;
 } SvgfPlanarGBuffer;
 int svgf_planar_gbuffer(svgf_ctx *ctx, SvgfPlanarGBuffer *out);
+/* The same for a PIPELINED context whose producer runs on `stream` (ABI 0.9): instead of waiting for the device (what
+ * svgf_planar_gbuffer does on a pipelined context) it makes `stream` wait for exactly what still reads the planes it hands out — the
+ * end of the frame before last, whose levels read them as the current G-buffer, and the temporal pass of the last frame, which reads
+ * them as the previous one — so that the producer of frame n+1 runs beside the levels of frame n.  Use with inputs_ready = 2 and
+ * two streams in turn (producer, svgf_denoise_planar and the consumer of `output` of one frame on one stream).  Not under capture. */
+int svgf_planar_gbuffer_stream(svgf_ctx *ctx, SvgfPlanarGBuffer *out, void *stream);
 int svgf_denoise_planar(svgf_ctx *ctx, void *out_rgb_dev, const void *in_rgb_dev, const SvgfCamera *cam, const SvgfParams *p, void *stream);
 /* svgf_synth_render writing those planes instead of the AoS texel (same pixels, same values) */
 int svgf_synth_render_planar(int device, void *out_rgb_dev, const SvgfPlanarGBuffer *out_planes, int width, int height,

@@ -207,3 +207,60 @@ def test_planar_pointers_survive_a_reset_and_the_fused_first_level_reads_planes(
             for f in range(5):
                 assert np.array_equal(res[False][0][f], res[True][0][f]), f"variant {variant}, reset at {reset_at}: frame {f}"
             assert np.array_equal(res[False][1], res[True][1]) and np.array_equal(res[False][2], res[True][2])
+
+
+@pytest.mark.gpu
+def test_planar_frames_on_the_frame_pipeline(pkg):
+    """ABI 0.9: planar frames take the frame pipeline up.  (a) the promise (inputs_ready = 1) on a static scene whose planes of both
+    parities were filled once; (b) inputs_ready = 2 with two streams in turn and a producer that REFILLS the planes every frame
+    through svgf_planar_gbuffer_stream (its stream waits for the frames that still read them: the temporal pass of the last frame,
+    the levels of the frame before last) — both bit-identical to ordered planar frames."""
+    import torch
+    W, H, N = 640, 360, 12
+    base = pkg.reference_defaults().set(temporal_enable=1, spatial_enable=1, atrous_nlevel=5, history_level=1)
+    cams = [pkg.synth.camera_for_frame(f, True) for f in range(N)]
+    res = {}
+    for mode in ("ordered", "two-streams"):
+        d = pkg.Denoiser(W, H, 0, pipelined=(mode != "ordered"))
+        assert mode == "ordered" or d.pipeline_status() == 1, d.last_error()
+        p = pkg.SvgfParams.from_buffer_copy(base).set(inputs_ready=0 if mode == "ordered" else 2)
+        st = [torch.cuda.Stream(), torch.cuda.Stream()]
+        rgb = [torch.empty((H, W, 3), dtype=torch.float32, device="cuda") for _ in range(2)]
+        out = [torch.empty((H, W, 3), dtype=torch.float32, device="cuda") for _ in range(2)]
+        keep = [torch.empty((H, W, 3), dtype=torch.float32, device="cuda") for _ in range(N)]
+        torch.cuda.synchronize()
+        for f in range(N):
+            q = (f & 1) if mode != "ordered" else 0
+            with torch.cuda.stream(st[q]):
+                planes = d.planar_gbuffer(stream=st[q]) if mode != "ordered" else d.planar_gbuffer()
+                pkg.binding.synth_render_planar(rgb[q], planes, W, H, cams[f], f, seed=19, stream=st[q])
+                d.denoise_planar(out[q], rgb[q], cams[f], p, stream=st[q])
+                keep[f].copy_(out[q], non_blocking=True)
+        torch.cuda.synchronize()
+        assert mode == "ordered" or d.is_pipelined()
+        res[mode] = ([k.cpu().numpy() for k in keep], d.read_state(0), d.read_state(1), d.read_state(2))
+        d.free()
+    for f in range(N):
+        assert np.array_equal(res["ordered"][0][f], res["two-streams"][0][f]), f"frame {f}"
+    for a, b in zip(res["ordered"][1:], res["two-streams"][1:]):
+        assert np.array_equal(a, b)
+    # (a) static scene, planes of both parities filled once, every frame promised
+    cam = pkg.synth.camera_for_frame(0, False)
+    got = {}
+    for promised in (False, True):
+        d = pkg.Denoiser(W, H, 0, pipelined=promised)
+        p = pkg.SvgfParams.from_buffer_copy(base).set(inputs_ready=1 if promised else 0)
+        rgb = torch.empty((H, W, 3), dtype=torch.float32, device="cuda")
+        outs = [torch.empty((H, W, 3), dtype=torch.float32, device="cuda") for _ in range(10)]
+        for _ in range(2):
+            pkg.binding.synth_render_planar(rgb, d.planar_gbuffer(), W, H, cam, 0, seed=23)
+            d.denoise_planar(outs[0], rgb, cam, p)
+        torch.cuda.synchronize()
+        for k in range(10):
+            d.denoise_planar(outs[k], rgb, cam, p)
+        d.sync()
+        got[promised] = [o.cpu().numpy() for o in outs]
+        assert d.is_pipelined() == promised
+        d.free()
+    for k in range(10):
+        assert np.array_equal(got[False][k], got[True][k]), f"promised planar frame {k}"
