@@ -10,6 +10,11 @@ import __graft_entry__ as ge
 import telemetry
 pkg = ge.load_package()
 size = sys.argv[1] if len(sys.argv) > 1 else "1920x1080"
+knobs = [a for a in sys.argv[2:] if "=" in a]      # name=value: svgf_exp_set knobs -> the experiments build of the library is used
+if knobs:
+    pkg.binding.use_experiments_library(True)
+    for kv in knobs:
+        k, v = kv.split("="); pkg.binding.exp_set(k, int(v))
 W, H = map(int, size.split("x"))
 dev = torch.device("cuda", 0)
 cam = [pkg.synth.camera_for_frame(f, False) for f in range(4)]
@@ -40,7 +45,7 @@ def sustain(mode, sec):
         if k % 128 == 0: torch.cuda.synchronize()
     torch.cuda.synchronize()
 tm = telemetry.Sampler(0, period_s=0.004).start()
-res = {"lib_sha": __import__("hashlib").sha256(open(pkg.binding.LIB_PATH, "rb").read()).hexdigest()[:10], "size": size}
+res = {"knobs": knobs, "lib_sha": __import__("hashlib").sha256(open(pkg.binding.LIB_PATH, "rb").read()).hexdigest()[:10], "size": size}
 for mode in ("O", "P"):
     sustain(mode, 0.5)
     t0 = time.perf_counter()
