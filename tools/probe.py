@@ -15,6 +15,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tools"))
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 import __graft_entry__ as ge  # noqa: E402
 import telemetry  # noqa: E402
 
@@ -48,7 +49,7 @@ def main():
     out = torch.empty((H, W, 3), dtype=torch.float32, device="cuda")
     results = {}
     for v in [int(x) for x in a.variants.split(",")]:
-        d = pkg.Denoiser(W, H, 0, experiments=v in (5, 6))      # parked variants live in libsvgf_hip_exp.so (SVGF_USE_EXPERIMENTS_LIB=1: everything does)
+        d = pkg.Denoiser(W, H, 0, experiments=v in (5, 6), pipelined=a.overlap != 0)      # parked variants live in libsvgf_hip_exp.so
         p = pkg.reference_defaults().set(temporal_enable=1, spatial_enable=1, atrous_nlevel=a.nlevel, kernel_variant=v, inputs_ready=a.overlap, blur_variance=a.blur)
         if a.planar:      # both plane sets (they alternate with the history) get the static scene's G-buffer; d.denoise then means denoise_planar
             cam_dict = pkg.synth.camera_for_frame(0, False)

@@ -1,18 +1,18 @@
 #!/usr/bin/env python3
 """Soak test: two contexts fed the same device-produced moving-camera sequence on two streams, thousands of frames without
 a synchronisation between calls, parameters redrawn every K frames (--random K).
-  --pair default-fused (the default): context A runs the default path (temporal pass + lane kernels), context B forces the fused
-        temporal + first-level kernel (kernel_variant 6; it falls back to the unfused path by itself for parameter draws it
-        does not support).  Outputs must agree to 1e-5 relative at every check (1e-4 while levels 6+ are on: steps >= 64), history
-        lengths bit for bit.
-  --pair default-gather: B runs the strict gather kernel on every level (kernel_variant 1): <= 1e-5.
-  --pair same: both default (since round 4 SvgfParams::inputs_ready is ignored, so this is the old overlap soak's shape):
-        bit-identical.
-usage: soak.py [--size 1920x1080] [--frames 2000] [--random 25] [--pair default-fused]"""
+Context A is always a PIPELINED context (svgf_create_ex(SVGF_CREATE_PIPELINED)) whose frames carry the inputs_ready = 1 promise.
+  --pair same (the default): context B runs the same frames ordered on its stream (inputs_ready = 0): bit-identical at every check.
+  --pair default-gather: B runs the strict gather kernel on every level (kernel_variant 1): <= 1e-5 relative (1e-4 while levels
+        6+ are on: steps >= 64), history lengths bit for bit.
+  --pair default-fused: B forces the parked fused temporal + first-level kernel of the experiments build (kernel_variant 6; it
+        falls back to the unfused path by itself for parameter draws it does not support): <= 1e-5.
+usage: soak.py [--size 1920x1080] [--frames 2000] [--random 25] [--pair same]"""
 import argparse
 import os
 import sys
 
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")      # the pipelined context's two internal streams on hardware queues of their own (include/svgf.h)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import __graft_entry__ as ge  # noqa: E402
@@ -25,13 +25,14 @@ def main():
     ap.add_argument("--random", type=int, default=0, metavar="K",
                     help="every K frames draw new parameters (levels 0..8, history level, paper steps, pre-blur, debug views, "
                          "temporal on/off) for both contexts")
-    ap.add_argument("--pair", default="default-fused", choices=["default-fused", "default-gather", "same"])
+    ap.add_argument("--pair", default="same", choices=["default-fused", "default-gather", "same"])
     a = ap.parse_args()
     import torch
     pkg = ge.load_package()
     W, H = map(int, a.size.split("x"))
     vb = {"default-fused": 6, "default-gather": 1, "same": 0}[a.pair]
-    da, db = pkg.Denoiser(W, H), pkg.Denoiser(W, H, experiments=(vb == 6))      # (the parked fused kernel lives in libsvgf_hip_exp.so)
+    da, db = pkg.Denoiser(W, H, pipelined=True), pkg.Denoiser(W, H, experiments=(vb == 6))      # (the parked fused kernel lives in libsvgf_hip_exp.so)
+    print(f"context A: pipeline status {da.pipeline_status()} {da.last_error()}")
     pa = pkg.reference_defaults().set(temporal_enable=1, spatial_enable=1, atrous_nlevel=5, history_level=1, inputs_ready=1)
     pb = pkg.reference_defaults().set(temporal_enable=1, spatial_enable=1, atrous_nlevel=5, history_level=1, inputs_ready=0, kernel_variant=vb)
     nbuf = 64    # a 64-frame moving-camera sequence produced up front and replayed, so calls go back to back
