@@ -454,7 +454,11 @@ def main():
     t_warm_end = time.perf_counter()
     den.profile_enable(a.steps)
     t_region0 = time.perf_counter()
-    dt, pixels = pkg.farm.timed_region(step, a.steps, 0, lambda: torch.cuda.synchronize(dev), dist=dist, device=None if share_device else dev)
+    # N > 1: the ranks' warm-ups and trials end at different times; they meet on a host-side (gloo) group while their GPUs keep running
+    # untimed frames (farm.timed_region), then the bracketing barrier + synchronisation, then the K timed steps
+    busy_group = dist.new_group(backend="gloo") if (dist is not None and world > 1) else None
+    dt, pixels = pkg.farm.timed_region(step, a.steps, 0, lambda: torch.cuda.synchronize(dev), dist=dist, device=None if share_device else dev,
+                                       busy_group=busy_group)
     t_region1 = time.perf_counter()
     if os.environ.get("SVGF_BENCH_DEBUG"):
         dbg = [region(step, a.steps) for _ in range(4)]

@@ -23,12 +23,26 @@ def last_local_seconds() -> float:
     return _last_local
 
 
-def timed_region(step_fn, steps: int, warmup: int, sync_fn, dist=None, device=None):
+def timed_region(step_fn, steps: int, warmup: int, sync_fn, dist=None, device=None, busy_group=None):
     """Run `warmup` untimed steps, then time exactly `steps` steps bracketed by barrier + device sync on both sides.
-    Returns (max-over-ranks seconds, sum-over-ranks of the per-step work units returned by step_fn)."""
+    Returns (max-over-ranks seconds, sum-over-ranks of the per-step work units returned by step_fn).
+
+    busy_group (a host-side process group, gloo): the ranks first meet WITHOUT idling their GPUs — each posts an asynchronous barrier on
+    that group and keeps running untimed steps until it completes — so that the bracketing barrier below finds every rank within a
+    few frames of the others.  A rank that waits at a plain barrier for a slower one idles its GPU, and an MI355X that has idled for
+    5 / 20 ms runs the next frames 7 / 18 % slower: the MAX over ranks would then be set by whoever arrived FIRST."""
     import torch
     for i in range(warmup):
         step_fn(i)
+    if dist is not None and busy_group is not None:
+        w = dist.barrier(group=busy_group, async_op=True)
+        k = 0
+        while not w.is_completed():
+            step_fn(warmup + k)
+            k += 1
+            if k % 8 == 0:
+                sync_fn()          # bounds the queue: at most 8 untimed frames are in flight when the last rank arrives
+        w.wait()
     sync_fn()
     if dist is not None:
         dist.barrier()

@@ -33,8 +33,18 @@ def _worker(rank, world, port, q):
             px += W * H
         return px
 
-    dt, units = pkg.farm.timed_region(step, steps=3, warmup=1, sync_fn=lambda: None, dist=dist)
-    q.put((rank, mine, dt, units, checks))
+    calls = [0]
+
+    def counted(i):
+        calls[0] += 1
+        return step(i)
+
+    busy = dist.new_group(backend="gloo")      # (a collective itself: both ranks are here)
+    if rank == 1:
+        import time
+        time.sleep(0.3)           # rank 0 arrives first and must keep stepping (untimed) until rank 1 is there
+    dt, units = pkg.farm.timed_region(counted, steps=3, warmup=1, sync_fn=lambda: None, dist=dist, busy_group=busy)
+    q.put((rank, mine, dt, units, checks, calls[0]))
     dist.destroy_process_group()
 
 
@@ -58,11 +68,13 @@ def test_two_rank_farm():
     import __graft_entry__ as ge
     pkg = ge.load_package(); orc = ge.load_oracle()
     p = pkg.reference_defaults().set(temporal_enable=1, spatial_enable=1, atrous_nlevel=2)
-    for (_, mine, _, _, checks) in res:
+    # the rank that arrived early kept its engine busy with untimed steps while it waited (busy_group); only 3 steps were timed on both
+    assert res[0][5] > res[1][5] >= 4 and res[0][3] == 3 * 5 * 24 * 16
+    for (_, mine, _, _, checks, ncalls) in res:
         for s in mine:
             o = orc.Oracle(pkg, 24, 16)
             fr = pkg.synth.render_frame(24, 16, 0, seed=100 + s)
-            for _ in range(4):
+            for _ in range(ncalls):          # warm-up + the untimed steps of the rendezvous + the 3 timed ones
                 out = o.denoise(*fr, p)
             o.free()
             assert np.isclose(float(out.sum()), checks[s], rtol=0, atol=0)
