@@ -73,10 +73,11 @@ def build_hip(force: bool = False, experiments: bool = False) -> str:
 
 
 def build_examples(force: bool = False) -> str:
-    """examples/farm.cpp (N contexts on N GPUs from one C++ process) and examples/pipeline.cpp (a renderer's frame loop on the frame
-    pipeline), through the C ABI -> examples/farm, examples/pipeline, linked against the product library in-tree."""
+    """examples/farm.cpp (N contexts on N GPUs from one C++ process), examples/pipeline.cpp (a renderer's frame loop on the frame
+    pipeline) and examples/cadence.cpp (a fixed-rate loop + the effective shader clock), through the C ABI -> examples/farm,
+    examples/pipeline, examples/cadence, linked against the product library in-tree."""
     out = ""
-    for name in ("pipeline", "farm"):
+    for name in ("pipeline", "farm", "cadence"):
         src = os.path.join(ROOT, "examples", name + ".cpp")
         out = os.path.join(ROOT, "examples", name)
         if not force and _newer(out, [src, os.path.join(ROOT, "include", "svgf.h"), LIB]):

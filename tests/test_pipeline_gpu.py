@@ -196,6 +196,18 @@ def test_cpp_pipeline_example_is_bit_identical_to_frames_in_turn(pkg):
         assert r.returncode == 0 and "bit-identical: yes" in r.stdout and "[context pipelined]" in r.stdout, r.stdout
 
 
+def test_cpp_cadence_example_runs(pkg):
+    """examples/cadence.cpp: a fixed-rate frame loop (producer + denoise + pack per tick, GPU idle in between) with the shader-clock and
+    memory probes of DESIGN.md 6.2, through the C ABI."""
+    import os
+    import subprocess
+    from conftest import ROOT
+    exe = os.path.join(ROOT, "examples", "cadence")
+    assert os.path.exists(exe), "examples/cadence is built by __graft_entry__.build()"
+    r = subprocess.run([exe, "240", "24", "640", "360"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.count("ms per svgf_denoise") == 2 and "back to back" in r.stdout, r.stdout
+
+
 def test_two_alternating_streams_without_the_promise(pkg):
     """inputs_ready = 2: the pipeline, every frame ordered behind the stream it was given to.  Even frames on one stream, odd frames on
     another, the inputs of each frame COPIED into its buffers on that stream right before the call (so they are not complete at call
