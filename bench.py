@@ -266,6 +266,9 @@ def main():
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    # (created here, long before it is used: new_group is itself a collective, and a rank waiting in it right before the timed region
+    # would idle its GPU)
+    busy_group = dist.new_group(backend="gloo") if (dist is not None and world > 1) else None
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     torch.cuda.set_device(local_rank)
@@ -456,7 +459,6 @@ def main():
     t_region0 = time.perf_counter()
     # N > 1: the ranks' warm-ups and trials end at different times; they meet on a host-side (gloo) group while their GPUs keep running
     # untimed frames (farm.timed_region), then the bracketing barrier + synchronisation, then the K timed steps
-    busy_group = dist.new_group(backend="gloo") if (dist is not None and world > 1) else None
     dt, pixels = pkg.farm.timed_region(step, a.steps, 0, lambda: torch.cuda.synchronize(dev), dist=dist, device=None if share_device else dev,
                                        busy_group=busy_group)
     t_region1 = time.perf_counter()

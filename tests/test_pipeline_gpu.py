@@ -311,5 +311,5 @@ print('RESULT ' + json.dumps(res))
     res = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("RESULT ")][-1][7:])
     print(res)
     assert res["ordered_status"] == 0 and res["promised_status"] == 2 and "hardware queue" in res["promised_err"] and not res["promised_piped"]
-    assert res["promised"] <= 1.02 * res["ordered"], res
+    assert res["promised"] <= 1.03 * res["ordered"], res      # (both are ordered frames now: 0.2585 against 0.2579 measured)
     assert res["promised_sum"] == res["ordered_sum"]
