@@ -590,13 +590,17 @@ def main():
         c_g = torch.empty((H * W * 52,), dtype=torch.uint8, device=dev)
         ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(a.cadence_frames)]
         period = 1.0 / a.cadence_hz
-        den_o.profile_stride(1)
-        den_o.profile_enable(a.cadence_frames)      # the kernels' own durations in this state (dispatch timestamps), beside kernels_us
+        n_prof = 12      # further ticks behind the timed ones, with an event pair on every dispatch: the kernels' own durations in this state
+        ev += [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(n_prof)]
+        den_o.profile_enable(0)
         torch.cuda.synchronize(dev)
         t_cad0 = time.perf_counter()
         nxt = t_cad0
         host_ms = []
-        for f in range(a.cadence_frames):
+        for f in range(a.cadence_frames + n_prof):
+            if f == a.cadence_frames:
+                den_o.profile_stride(1)
+                den_o.profile_enable(n_prof)
             while time.perf_counter() < nxt:
                 time.sleep(0.0002)
             nxt += period
@@ -612,7 +616,7 @@ def main():
             den_o.sync_stream(stream)          # the frame is on the screen before the next one starts (a renderer's swap)
             host_ms.append((time.perf_counter() - th0) * 1e3)
         t_cad1 = time.perf_counter()
-        cad_rows = [den_o.profile_read(f) for f in range(4, min(a.cadence_frames, den_o.profile_frames()))]
+        cad_rows = [den_o.profile_read(f) for f in range(min(n_prof, den_o.profile_frames()))]
         cad_t = [ms for r in cad_rows for kind, ms in r if kind == pkg.binding.KERNEL_TEMPORAL]
         cad_l = [ms for r in cad_rows for kind, ms in r if kind in (pkg.binding.KERNEL_ATROUS, pkg.binding.KERNEL_FUSED)]
         den_o.profile_enable(0)
@@ -621,7 +625,7 @@ def main():
         cadence = {"hz": a.cadence_hz, "frames": a.cadence_frames - 4, "ms_per_step": round(float(np.median(den_ms)), 5),
                    "ms_per_step_p10_p90": [round(float(np.quantile(den_ms, 0.1)), 5), round(float(np.quantile(den_ms, 0.9)), 5)],
                    "frame_ms_producer_denoise_pack": round(float(np.median(frm_ms)), 5),
-                   "host_ms_enqueue_to_done": round(float(np.median(host_ms[4:])), 5),
+                   "host_ms_enqueue_to_done": round(float(np.median(host_ms[4:a.cadence_frames])), 5),
                    "kernels_us": {"temporal": round(float(np.mean(cad_t)) * 1e3, 2) if cad_t else None,
                                   "atrous_level_mean": round(float(np.mean(cad_l)) * 1e3, 2) if cad_l else None,
                                   "vs_sustained": {"temporal": round(float(np.mean(cad_t)) / float(np.mean(iso_temporal_ms)), 3) if (cad_t and iso_temporal_ms) else None,
@@ -629,8 +633,8 @@ def main():
                    "telemetry": tm_all.summary(t_cad0, t_cad1),
                    "what": "one frame per 1/hz s: svgf_synth_render + svgf_denoise (ordered, inputs_ready = 0) + svgf_display_pack on one stream, then the "
                            "stream is waited for and the GPU idles until the next tick; ms_per_step = HIP events around the svgf_denoise of each "
-                           "frame (median; the first 4 frames dropped): the same kernels as the sustained figure, in the power state "
-                           "an otherwise idle GPU is in (DESIGN.md 6.2)"}
+                           "frame (median; the first 4 frames dropped; no per-kernel events): the same kernels as the sustained figure, in the state "
+                           "a chip that idled a moment ago is in (DESIGN.md 6.2); kernels_us = the dispatches' own durations on 12 further ticks"}
     tm_all.stop()
     # config1 (non-temporal, ONE level): that level carries the prepare pass in its loader waves (one launch per frame, kind FUSED):
     # it is the a-trous launch of this configuration, timed with the prepare work inside it

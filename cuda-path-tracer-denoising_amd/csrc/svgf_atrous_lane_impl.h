@@ -42,11 +42,14 @@
 #ifndef SVGF_LANE_PRIO
 // progress-based wave priorities: stage order A (start, after 1/4, after 2/3 of the row), stage order B (start, 1/3, 2/3, 3/4).
 // Order B keeps the higher priority for longer: its waves are the ones that reach the barrier last (profiles/r03_ab_lane_prio.log:
-// 3,2,1 / 3,2,1,0 -> 3,2,1 / 3,3,2,1 is -1.5 % per level; no priorities at all +6 %)
-#define SVGF_LANE_PRIO 3, 2, 1, 3, 3, 2, 1
+// 3,2,1 / 3,2,1,0 -> 3,2,1 / 3,3,2,1 is -1.5 % per level; no priorities at all +6 %).  Round 6 (profiles/r06_ab_lane_prio.txt, 22
+// schedules on the A/B harness): order B holds 3 until 3/4 of its row and ends at 2, order A ends at 2 instead of 1, the loader
+// waves drop from 2 to 1: -1.5 % per 1080p level (40.2 -> 39.6 us), -0.5 % at 4K and 1280x720; lowering order A's start or holding its
+// 3 for longer LOSES 2-5 %
+#define SVGF_LANE_PRIO 3, 2, 2, 3, 3, 3, 2
 #endif
 #ifndef SVGF_LANE_LOADER_PRIO
-#define SVGF_LANE_LOADER_PRIO 2
+#define SVGF_LANE_LOADER_PRIO 1
 #endif
 
 namespace {
