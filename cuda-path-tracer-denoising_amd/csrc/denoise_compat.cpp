@@ -73,7 +73,7 @@ void denoise(glm::vec3 *output, glm::vec3 *input, GBufferTexel *gbuffer)
     // -DSVGF_COMPAT_NO_TRAILING_SYNC: return with the frame enqueued on the legacy default stream.  Everything pathtrace() does next
     // (sendTwoImagesToPBO on the same stream, src/pathtrace.cu:446; the blocking cudaMemcpy of the image, :449) is ordered behind it by
     // the stream, so results are unchanged; what goes away is one host round trip per frame (the PBO kernel is already queued when
-    // the last level ends: 0.296 -> 0.284 ms per 1080p frame for denoise + pack kernel + the caller's own sync, `latency_caller_ms` of
+    // the last level ends: 0.289 -> 0.278 ms per 1080p frame for denoise + pack kernel + the caller's own sync, `latency_caller_ms` of
     // bench.py's line, profiles/r06_bench_line_driver_cmd.json).
 #endif
     if (rc != SVGF_OK) fprintf(stderr, "denoise: svgf error %d: %s\n", rc, svgf_last_error(g_ctx));
