@@ -42,10 +42,11 @@ HBM_PEAK_GBS = 8000.0              # MI355X_MICROARCH.md: 8 TB/s spec
 
 
 def kernel_sources_sha16():
-    """Fingerprint of the a-trous kernel sources the PMC traffic record belongs to."""
+    """Fingerprint of the a-trous KERNEL sources the PMC traffic record belongs to (the host side, svgf_api.hip, holds no kernel code:
+    which kernel ran on which level is in the record itself, per level)."""
     import hashlib
     h = hashlib.sha256()
-    for name in ("svgf_atrous_lane_impl.h", "svgf_atrous_lane.hip", "svgf_atrous_prepare_fused.hip", "svgf_atrous_strip.hip", "svgf_api.hip"):
+    for name in ("svgf_atrous_lane_impl.h", "svgf_atrous_lane.hip", "svgf_atrous_prepare_fused.hip", "svgf_atrous_strip.hip"):
         with open(os.path.join(ROOT, "cuda-path-tracer-denoising_amd", "csrc", name), "rb") as f:
             h.update(f.read())
     return h.hexdigest()[:16]

@@ -32,7 +32,7 @@ EXPORTS = ["svgf_version", "svgf_params_default", "svgf_create", "svgf_destroy",
            "svgf_synth_camera", "svgf_synth_render", "svgf_scene_render", "svgf_scene_render_mesh", "svgf_display_pack", "svgf_save_png",
            "svgf_planar_gbuffer", "svgf_denoise_planar", "svgf_synth_render_planar", "svgf_params_sizeof", "svgf_scene_render_mesh_planar",
            "svgf_sync_stream", "svgf_build_has_experiments", "svgf_is_pipelined", "svgf_create_ex", "svgf_enable_pipeline",
-           "svgf_pipeline_status", "svgf_planar_gbuffer_stream"]
+           "svgf_pipeline_status", "svgf_planar_gbuffer_stream", "svgf_streams_overlap"]
 CREATE_PIPELINED = 1
 
 
@@ -146,6 +146,8 @@ def load_library(path: str | None = None, experiments: bool = False):
     lib.svgf_enable_pipeline.argtypes = [vp]
     lib.svgf_pipeline_status.argtypes = [vp]
     lib.svgf_pipeline_status.restype = ip
+    lib.svgf_streams_overlap.argtypes = [ip, vp, vp]
+    lib.svgf_streams_overlap.restype = ip
     lib.svgf_destroy.argtypes = [vp]
     lib.svgf_reset.argtypes = [vp]
     lib.svgf_denoise.argtypes = [vp, vp, vp, vp, C.POINTER(SvgfCamera), C.POINTER(SvgfParams), vp]
@@ -334,6 +336,17 @@ class Denoiser:
 
 
 # --- the denoiser's inputs produced on the device -------------------------------------------
+def streams_overlap(stream_a, stream_b, device: int = 0) -> bool:
+    """svgf_streams_overlap: do kernels on the caller's two streams run side by side (what inputs_ready = 2 needs)?"""
+    lib = load_library()
+    sa = stream_a if isinstance(stream_a, int) else stream_a.cuda_stream
+    sb = stream_b if isinstance(stream_b, int) else stream_b.cuda_stream
+    rc = lib.svgf_streams_overlap(int(device), sa, sb)
+    if rc < 0:
+        raise SvgfError(f"svgf_streams_overlap failed ({rc})")
+    return bool(rc)
+
+
 def synth_camera(frame: int, moving: bool, width: int, height: int):
     """svgf_synth_camera: (SvgfCamera, (plx, ply)) computed by the library (C float math)."""
     lib = load_library()

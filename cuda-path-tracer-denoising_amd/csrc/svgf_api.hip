@@ -537,42 +537,66 @@ __global__ void k_svgf_spin(unsigned long long ticks)
 // (default 4, read when the runtime starts); two streams that land on the same queue run their kernels one after the other, and
 // pipelined frames are then 8-10 % SLOWER than ordered ones (the cross-stream events cost, nothing overlaps: profiles/r05_exp_pipeline.log).
 // Two one-wave spin kernels of ~200 us, one per stream: together they take ~200 us on two queues and ~400 us on one.
-static int probe_streams_overlap(svgf_ctx *c, bool *overlap, double *ratio_out)
+static hipError_t probe_two_streams(int device, hipStream_t sa, hipStream_t sb, bool *overlap, double *ratio_out)
 {
     int khz = 0;
-    if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, c->device) != hipSuccess || khz <= 0) khz = 100000;
+    if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, device) != hipSuccess || khz <= 0) khz = 100000;
     const double spin_us = 200.0;
     const unsigned long long ticks = (unsigned long long)(spin_us * 1e-6 * khz * 1e3);
-    hipEvent_t e[4];
-    for (int k = 0; k < 4; k++) HIPC(c, hipEventCreate(&e[k]));
+    hipEvent_t e[4] = { nullptr, nullptr, nullptr, nullptr };
+    hipError_t rc = hipSuccess;
+    for (int k = 0; k < 4 && rc == hipSuccess; k++) rc = hipEventCreate(&e[k]);
     double best = 1e30;
-    for (int trial = 0; trial < 4; trial++) {       // trial 0 loads the code object
-        HIPC(c, hipDeviceSynchronize());
-        HIPC(c, hipEventRecord(e[0], c->pipe[0]));
-        hipLaunchKernelGGL(k_svgf_spin, dim3(1), dim3(64), 0, c->pipe[0], trial ? ticks : 1ull);
-        HIPC(c, hipEventRecord(e[1], c->pipe[0]));
-        HIPC(c, hipEventRecord(e[2], c->pipe[1]));
-        hipLaunchKernelGGL(k_svgf_spin, dim3(1), dim3(64), 0, c->pipe[1], trial ? ticks : 1ull);
-        HIPC(c, hipEventRecord(e[3], c->pipe[1]));
-        HIPC(c, hipGetLastError());
-        HIPC(c, hipDeviceSynchronize());
-        if (!trial) continue;
+#define SVGF_PROBE(call) do { if (rc == hipSuccess) rc = (call); } while (0)
+    for (int trial = 0; trial < 4 && rc == hipSuccess; trial++) {       // trial 0 loads the code object
+        SVGF_PROBE(hipDeviceSynchronize());
+        SVGF_PROBE(hipEventRecord(e[0], sa));
+        if (rc == hipSuccess) hipLaunchKernelGGL(k_svgf_spin, dim3(1), dim3(64), 0, sa, trial ? ticks : 1ull);
+        SVGF_PROBE(hipEventRecord(e[1], sa));
+        SVGF_PROBE(hipEventRecord(e[2], sb));
+        if (rc == hipSuccess) hipLaunchKernelGGL(k_svgf_spin, dim3(1), dim3(64), 0, sb, trial ? ticks : 1ull);
+        SVGF_PROBE(hipEventRecord(e[3], sb));
+        SVGF_PROBE(hipGetLastError());
+        SVGF_PROBE(hipDeviceSynchronize());
+        if (!trial || rc != hipSuccess) continue;
         // span from the earlier start to the later end, on the device's own clock
         float a01 = 0, a23 = 0, a03 = 0, a21 = 0;
-        HIPC(c, hipEventElapsedTime(&a01, e[0], e[1]));
-        HIPC(c, hipEventElapsedTime(&a23, e[2], e[3]));
-        HIPC(c, hipEventElapsedTime(&a03, e[0], e[3]));
-        HIPC(c, hipEventElapsedTime(&a21, e[2], e[1]));
+        SVGF_PROBE(hipEventElapsedTime(&a01, e[0], e[1]));
+        SVGF_PROBE(hipEventElapsedTime(&a23, e[2], e[3]));
+        SVGF_PROBE(hipEventElapsedTime(&a03, e[0], e[3]));
+        SVGF_PROBE(hipEventElapsedTime(&a21, e[2], e[1]));
         double span = a03 > a21 ? a03 : a21;
         if (a01 > span) span = a01;
         if (a23 > span) span = a23;
         const double one = (a01 < a23 ? a01 : a23);
         if (one > 0 && span / one < best) best = span / one;
     }
-    for (int k = 0; k < 4; k++) (void)hipEventDestroy(e[k]);
+#undef SVGF_PROBE
+    for (int k = 0; k < 4; k++) if (e[k]) (void)hipEventDestroy(e[k]);
     *ratio_out = best;
     *overlap = best < 1.5;          // 1.0: side by side; 2.0: one after the other
+    return rc;
+}
+
+static int probe_streams_overlap(svgf_ctx *c, bool *overlap, double *ratio_out)
+{
+    HIPC(c, probe_two_streams(c->device, c->pipe[0], c->pipe[1], overlap, ratio_out));
     return SVGF_OK;
+}
+
+// The same probe for a CALLER's two streams (inputs_ready = 2: the library runs such frames on the streams it is given and cannot
+// know how the runtime mapped them to hardware queues).  Synchronises the device: call it once, at set-up.
+extern "C" int svgf_streams_overlap(int device, void *stream_a, void *stream_b)
+{
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return SVGF_ERR_NO_DEVICE;
+    if (stream_a == stream_b) return 0;
+    SvgfDeviceGuard dev_guard(device);
+    if (!dev_guard.ok) return SVGF_ERR_NO_DEVICE;
+    bool overlap = false;
+    double ratio = 0.0;
+    if (probe_two_streams(device, (hipStream_t)stream_a, (hipStream_t)stream_b, &overlap, &ratio) != hipSuccess) return SVGF_ERR_HIP;
+    return overlap ? 1 : 0;
 }
 
 static int enable_pipeline(svgf_ctx *c)

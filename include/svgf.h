@@ -185,6 +185,12 @@ int svgf_enable_pipeline(svgf_ctx *ctx);
  *    svgf_last_error(ctx) holds the explanation right after svgf_create_ex / svgf_enable_pipeline. */
 int svgf_pipeline_status(const svgf_ctx *ctx);
 
+/* The library's queue probe for a CALLER's two streams (what inputs_ready = 2 runs on): 1 = kernels enqueued on `stream_a` and `stream_b`
+ * run side by side, 0 = the HIP runtime has put the two streams on one hardware queue and they run one after the other (frames in
+ * turn on them then gain nothing and pay a few per cent: use one stream and inputs_ready = 0 instead, as examples/farm.cpp and
+ * examples/pipeline.cpp do), < 0 = error.  Two 200 us one-wave kernels and two device synchronisations: call it once, at set-up. */
+int svgf_streams_overlap(int device, void *stream_a, void *stream_b);
+
 /* denoiseFree equivalent (src/denoise.cu:63-74).  NULL is accepted. */
 int svgf_destroy(svgf_ctx *ctx);
 

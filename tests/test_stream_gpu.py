@@ -148,3 +148,31 @@ def test_cpp_farm_example_eight_contexts_from_one_process(pkg):
     eight, one = run(8), run(1)
     assert len(set(eight.values())) == 8, eight
     assert eight[0] == one[0]
+    # every context pipelines its own sequence (two streams in turn); with the last argument 0 its frames are ordered on one stream: same result
+    r = subprocess.run([exe, "2", "5", "640", "360", "0"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+    assert r.returncode == 0 and "ordered on one stream" in r.stdout, r.stdout
+    m = re.search(r"context 0 device \d+ frames 5 ms_per_frame [0-9.]+ checksum ([-0-9.]+)", r.stdout)
+    assert m and m.group(1) == one[0], r.stdout
+
+
+def test_streams_overlap_probe_for_the_callers_streams(pkg):
+    """svgf_streams_overlap: the library's hardware-queue probe for a CALLER's two streams (what inputs_ready = 2 runs on).  With
+    GPU_MAX_HW_QUEUES=1 (a subprocess: the runtime reads it at start-up) any two streams serialise -> 0; the same stream twice -> 0; and
+    examples/farm then orders each context's frames on one stream and says so."""
+    import os
+    import subprocess
+    import sys
+    import torch
+    from conftest import ROOT
+    s0, s1 = torch.cuda.Stream(), torch.cuda.Stream()
+    assert pkg.binding.streams_overlap(s0, s0) is False
+    assert pkg.binding.streams_overlap(s0, s1) in (True, False)          # whatever the runtime's mapping is in this process: a clean answer
+    code = ("import sys; sys.path.insert(0, %r); import torch, __graft_entry__ as ge; pkg = ge.load_package(); "
+            "print('OVERLAP', int(pkg.binding.streams_overlap(torch.cuda.Stream(), torch.cuda.Stream())))" % ROOT)
+    r = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300, env=dict(os.environ, GPU_MAX_HW_QUEUES="1"))
+    assert r.returncode == 0 and "OVERLAP 0" in r.stdout, r.stdout + r.stderr[-1000:]
+    r = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300, env=dict(os.environ, GPU_MAX_HW_QUEUES="8"))
+    assert r.returncode == 0 and "OVERLAP 1" in r.stdout, r.stdout + r.stderr[-1000:]
+    r = subprocess.run([os.path.join(ROOT, "examples", "farm"), "1", "6", "640", "360", "1"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300,
+                       env=dict(os.environ, GPU_MAX_HW_QUEUES="1"))
+    assert r.returncode == 0 and "share a hardware queue" in r.stdout, r.stdout
