@@ -359,9 +359,11 @@ def main():
             torch.cuda.synchronize(dev)
 
     cur = {"den": den, "params": params}      # what the timed steps run on (the pipeline trial below may swap in the ordered twin)
+    calls = {"n": 0}                          # every frame this process has enqueued (warm-up, trial, settling, timed, other legs)
 
     def step(i):
         k = i % nsrc
+        calls["n"] += 1
         if a.planar_inputs:
             cur["den"].denoise_planar(outs[i & 1], d_in[k], cams[k], cur["params"], stream=stream)
         else:
@@ -370,6 +372,7 @@ def main():
 
     def step_ordered(i):
         k = i % nsrc
+        calls["n"] += 1
         if a.planar_inputs:
             den_o.denoise_planar(outs[i & 1], d_in[k], cams[k], op, stream=stream)
         else:
@@ -421,6 +424,7 @@ def main():
 
     def step_pipe(i):
         k = i % nsrc
+        calls["n"] += 1
         if a.planar_inputs:
             den.denoise_planar(outs[i & 1], d_in[k], cams[k], params, stream=stream)
         else:
@@ -456,6 +460,7 @@ def main():
         settle(step, 0.3)         # the chosen way, back to back, right up to the timed region
     den_first, den = den, cur["den"]
     t_warm_end = time.perf_counter()
+    untimed_before = calls["n"]
     den.profile_enable(a.steps)
     t_region0 = time.perf_counter()
     # N > 1: the ranks' warm-ups and trials end at different times; they meet on a host-side (gloo) group while their GPUs keep running
@@ -679,6 +684,9 @@ def main():
                        else "SVGF Mpixels/s (full pipeline) at 1080p; \u00e0-trous HBM GB/s vs roofline"),
             "value": round(value, 2), "unit": "Mpixels/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "warmup_steps_run": n_w,
+            # every frame this process ran before the K timed ones: the warm-up (>= --warmup steps and >= --min-warmup-seconds), the trial's
+            # regions and the settling stretches (0.25 s each way + 0.3 s of the chosen way)
+            "untimed_steps_before_timed_region": untimed_before,
             "ms_per_step": round(dt / a.steps * 1e3, 5), "higher_is_better": True, "scaling": "weak",
             # which state of the GPU the K timed steps ran in: "sustained" = directly behind >= min_warmup_seconds of
             # back-to-back frames; `cold_ms_per_step` = the first 12 frames of this process (rank 0), for comparison
