@@ -14,7 +14,8 @@
 //   examples/farm [contexts=8] [frames=64] [width=3840] [height=2160] [pipelined=1]
 //
 // Prints one line per context (device, frames, ms per frame, a checksum of the last output) and the aggregate Mpixels/s =
-// pixels of all contexts / the slowest context's time — the same reduction bench.py does across processes.
+// pixels of all contexts / the time from the first context's first frame to the last context's last — what bench.py's barrier-bracketed
+// MAX-time / SUM-pixels reduction measures across processes.
 #include <hip/hip_runtime.h>
 
 #include <chrono>
@@ -25,7 +26,29 @@
 
 #include "svgf.h"
 
-struct Result { int device = -1; int pipelined = 0; int rc = 0; double seconds = 0.0; double checksum = 0.0; char err[256] = ""; };
+struct Result { int device = -1; int pipelined = 0; int rc = 0; double seconds = 0.0; double t_start = 0.0, t_end = 0.0; double checksum = 0.0; char err[256] = ""; };
+
+
+// Two streams whose kernels really run side by side.  The HIP runtime spreads a process's streams over its hardware queues
+// (GPU_MAX_HW_QUEUES, default 4) in an order of its own, and two streams created one after the other may land on ONE queue; frames in
+// turn on such a pair gain nothing and pay a few per cent.  The library's probe (svgf_streams_overlap: two 200 us kernels, side by side
+// or one after the other?) says; on a miss another stream is created and tried, the rejected ones are destroyed at the end.
+// Returns 1 with st[0], st[1] set, or 0 with only st[0] (order the frames on it).
+static int two_overlapping_streams(int device, hipStream_t st[2])
+{
+    st[0] = st[1] = nullptr;
+    if (hipStreamCreateWithFlags(&st[0], hipStreamNonBlocking) != hipSuccess) return 0;
+    hipStream_t rejected[6];
+    int n_rejected = 0, found = 0;
+    for (int k = 0; k < 6 && !found; k++) {
+        hipStream_t cand = nullptr;
+        if (hipStreamCreateWithFlags(&cand, hipStreamNonBlocking) != hipSuccess) break;
+        if (svgf_streams_overlap(device, st[0], cand) == 1) { st[1] = cand; found = 1; }
+        else rejected[n_rejected++] = cand;
+    }
+    for (int k = 0; k < n_rejected; k++) (void)hipStreamDestroy(rejected[k]);
+    return found;
+}
 
 static void run_context(int k, int device, int W, int H, int frames, int pipelined, Result *r)
 {
@@ -44,12 +67,14 @@ static void run_context(int k, int device, int W, int H, int frames, int pipelin
         bool ok = true;
         for (int q = 0; q < 2 && ok; q++)
             ok = hipMalloc((void **)&rgb[q], n * 12) == hipSuccess && hipMalloc((void **)&out[q], n * 12) == hipSuccess &&
-                 hipMalloc(&gbuf[q], n * sizeof(SvgfGBufferTexel)) == hipSuccess && hipStreamCreateWithFlags(&st[q], hipStreamNonBlocking) == hipSuccess;
+                 hipMalloc(&gbuf[q], n * sizeof(SvgfGBufferTexel)) == hipSuccess;
         if (!ok) { fail("device buffers", SVGF_ERR_OOM); break; }
-        // two streams in turn only pay when the runtime has put them on different hardware queues (GPU_MAX_HW_QUEUES, and whatever
-        // else the process has created): ask the library's probe FIRST, and create a plain context whose frames are ordered on one
-        // stream otherwise (an ordered frame of a pipelined context would still pay the pipeline's events: 2 %)
-        if (pipelined && svgf_streams_overlap(device, st[0], st[1]) != 1) pipelined = 0;
+        // two streams in turn only pay when the runtime has put them on different hardware queues: pick such a pair FIRST (the library's
+        // probe), and create a plain context whose frames are ordered on one stream when there is none (an ordered frame of a
+        // pipelined context would still pay the pipeline's events: 2 %)
+        const int overlap = two_overlapping_streams(device, st);
+        if (!st[0]) { fail("hipStreamCreate", SVGF_ERR_HIP); break; }
+        if (!overlap) { pipelined = 0; st[1] = nullptr; }
         r->pipelined = pipelined;
         if (int rc = svgf_create_ex(device, W, H, pipelined ? SVGF_CREATE_PIPELINED : 0u, &ctx)) { fail("svgf_create_ex", rc); break; }
         SvgfParams p;
@@ -68,8 +93,9 @@ static void run_context(int k, int device, int W, int H, int frames, int pipelin
         }
         if (r->rc) break;
         if (int rc = svgf_sync_stream(ctx, st[0])) { fail("svgf_sync_stream", rc); break; }      // this context's frames only
-        if (int rc = svgf_sync_stream(ctx, st[1])) { fail("svgf_sync_stream", rc); break; }
+        if (st[1]) { if (int rc = svgf_sync_stream(ctx, st[1])) { fail("svgf_sync_stream", rc); break; } }
         r->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        r->t_start = std::chrono::duration<double>(t0.time_since_epoch()).count(); r->t_end = r->t_start + r->seconds;
         std::vector<float> h(3 * n);          // the last output; checksum = sum of every 61st value over the whole image
         if (hipMemcpy(h.data(), out[(frames - 1) & 1], h.size() * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) { fail("hipMemcpy", SVGF_ERR_HIP); break; }
         for (size_t i = 0; i < h.size(); i += 61) r->checksum += h[i];
@@ -94,17 +120,18 @@ int main(int argc, char **argv)
     std::vector<std::thread> th;
     for (int k = 0; k < n_ctx; k++) th.emplace_back(run_context, k, k % n_dev, W, H, frames, pipelined, &res[k]);
     for (auto &t : th) t.join();
-    double slowest = 0.0;
+    double first_start = 1e300, last_end = 0.0;      // the contexts set themselves up (stream probe, allocation) at different speeds: wall time of the farm
     int bad = 0;
     for (int k = 0; k < n_ctx; k++) {
         if (res[k].rc) { bad++; printf("context %d device %d FAILED rc %d: %s\n", k, res[k].device, res[k].rc, res[k].err); continue; }
         printf("context %d device %d frames %d ms_per_frame %.4f checksum %.6f%s\n", k, res[k].device, frames, res[k].seconds / frames * 1e3, res[k].checksum,
-               (pipelined && !res[k].pipelined) ? "  [its two streams share a hardware queue: frames ordered on one]" : "");
-        if (res[k].seconds > slowest) slowest = res[k].seconds;
+               (pipelined && !res[k].pipelined) ? "  [no two streams on different hardware queues: frames ordered on one]" : "");
+        if (res[k].t_start < first_start) first_start = res[k].t_start;
+        if (res[k].t_end > last_end) last_end = res[k].t_end;
     }
     if (bad) return 1;
     printf("farm: %d contexts on %d device(s), %dx%d, %d frames each, %s: %.1f Mpixels/s aggregate (producer + denoiser)\n", n_ctx, n_dev, W, H, frames,
            pipelined ? "frames of a context in turn on two streams (pipeline)" : "frames of a context ordered on one stream",
-           (double)n_ctx * frames * W * H / slowest / 1e6);
+           (double)n_ctx * frames * W * H / (last_end - first_start) / 1e6);
     return 0;
 }

@@ -25,10 +25,15 @@ def _inputs(pkg, W, H, n, seed, moving=True):
     return fr, [torch.from_numpy(f[0]).cuda() for f in fr], [torch.from_numpy(f[1].view(np.uint8).reshape(-1)).cuda() for f in fr]
 
 
+_CREATE_LOCK = threading.Lock()
+
+
 def _run(pkg, W, H, fr, tin, tg, plist, stream=None, reset_at=()):
     """One context, one frame per entry of plist (SvgfParams), every frame its own output buffer."""
     import torch
-    d = pkg.Denoiser(W, H, 0, pipelined=any(p.inputs_ready for p in plist))      # (only a context created pipelined looks at inputs_ready)
+    with _CREATE_LOCK:      # (the queue probe of svgf_create_ex times two kernels: not beside another thread's frames — test_two_pipelined_contexts...)
+        torch.cuda.synchronize()
+        d = pkg.Denoiser(W, H, 0, pipelined=any(p.inputs_ready for p in plist))      # (only a context created pipelined looks at inputs_ready)
     assert not any(p.inputs_ready for p in plist) or d.pipeline_status() == 1, d.last_error()
     outs = [torch.empty((H, W, 3), dtype=torch.float32, device="cuda") for _ in plist]
     s = stream or torch.cuda.current_stream()

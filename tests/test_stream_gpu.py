@@ -175,4 +175,4 @@ def test_streams_overlap_probe_for_the_callers_streams(pkg):
     assert r.returncode == 0 and "OVERLAP 1" in r.stdout, r.stdout + r.stderr[-1000:]
     r = subprocess.run([os.path.join(ROOT, "examples", "farm"), "1", "6", "640", "360", "1"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300,
                        env=dict(os.environ, GPU_MAX_HW_QUEUES="1"))
-    assert r.returncode == 0 and "share a hardware queue" in r.stdout, r.stdout
+    assert r.returncode == 0 and "no two streams on different hardware queues" in r.stdout, r.stdout
