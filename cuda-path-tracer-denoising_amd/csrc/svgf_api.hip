@@ -630,6 +630,19 @@ static int enable_pipeline(svgf_ctx *c)
     bool overlap = true;
     double ratio = 0.0;
     if (const int rc = probe_streams_overlap(c, &overlap, &ratio); rc != SVGF_OK) return rc;
+    // The runtime hands out hardware queues in an order of its own, and two streams created one after the other can land on ONE queue
+    // even when the process has several (seen in fresh C++ processes under the default GPU_MAX_HW_QUEUES = 4, examples/): replace
+    // the second stream until the pair overlaps, a few times; with ONE queue in all, no replacement helps and the promise is refused.
+    hipStream_t rejected[5];
+    int n_rejected = 0;
+    for (int k = 0; k < 5 && !overlap; k++) {
+        hipStream_t cand = nullptr;
+        if (hipStreamCreateWithFlags(&cand, hipStreamNonBlocking) != hipSuccess) break;
+        rejected[n_rejected++] = c->pipe[1];
+        c->pipe[1] = cand;
+        if (const int rc = probe_streams_overlap(c, &overlap, &ratio); rc != SVGF_OK) break;
+    }
+    for (int k = 0; k < n_rejected; k++) (void)hipStreamDestroy(rejected[k]);
     HIPC(c, hipDeviceSynchronize());
     c->pipelined = 1;
     c->pipe_serial = overlap ? 0 : 1;
@@ -637,7 +650,7 @@ static int enable_pipeline(svgf_ctx *c)
     c->pipe_frames = 0; c->ev_hist_valid[0] = c->ev_hist_valid[1] = 0;
     c->ev_done_valid[0] = c->ev_done_valid[1] = 0;
     if (!overlap)
-        snprintf(c->err, sizeof(c->err), "frame pipeline: the context's two internal streams share a hardware queue (two 200 us kernels took %.2fx one): "
+        snprintf(c->err, sizeof(c->err), "frame pipeline: the context's internal streams share a hardware queue (six candidate pairs; two 200 us kernels took %.2fx one): "
                  "the inputs_ready = 1 promise is refused and such frames run ordered on the caller's stream; start the process with "
                  "GPU_MAX_HW_QUEUES=8 (read by the HIP runtime at initialisation)", ratio);
     return SVGF_OK;

@@ -114,7 +114,8 @@ typedef struct SvgfParams {
                                  (GPU_MAX_HW_QUEUES, default 4, read by the runtime when the process starts; a process that also holds
                                  an RCCL communicator or many streams of its own should export 8): on one queue pipelined frames are
                                  8-10 % SLOWER than ordered ones.  The library probes this when the resources are created (two 200 us
-                                 kernels, one per stream: side by side or one after the other?) and REFUSES the promise when they
+                                 kernels, one per stream: side by side or one after the other?), replaces its second stream up to five
+                                 times when the pair serialises, and REFUSES the promise when they still
                                  serialise — svgf_pipeline_status() == 2, svgf_last_error() says why, promised frames run as
                                  ordinary ordered frames.
                                  0 = everything ordered on `stream` (the reference's behaviour).

@@ -318,3 +318,22 @@ print('RESULT ' + json.dumps(res))
     assert res["ordered_status"] == 0 and res["promised_status"] == 2 and "hardware queue" in res["promised_err"] and not res["promised_piped"]
     assert res["promised"] <= 1.03 * res["ordered"], res      # (both are ordered frames now: 0.2585 against 0.2579 measured)
     assert res["promised_sum"] == res["ordered_sum"]
+
+
+def test_the_library_finds_an_overlapping_stream_pair_under_the_default_queue_setting(pkg):
+    """No GPU_MAX_HW_QUEUES in the environment (the HIP runtime's default: 4 hardware queues): two streams created one after the other
+    can land on one queue, so svgf_create_ex replaces its second internal stream until the pair overlaps.  Eight contexts in a fresh
+    process, some created behind other streams: every one ends with the promise honoured."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    code = ("import sys; sys.path.insert(0, %r); import torch, __graft_entry__ as ge; pkg = ge.load_package(); st = []\n"
+            "out = []\n"
+            "for k in range(8):\n"
+            "    d = pkg.Denoiser(320, 180, 0, pipelined=True); out.append(d.pipeline_status()); st.append(torch.cuda.Stream()); d.free()\n"
+            "print('STATUS', out)" % ROOT)
+    env = dict(os.environ)
+    env.pop("GPU_MAX_HW_QUEUES", None)
+    r = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300, env=env)
+    assert r.returncode == 0 and "STATUS [1, 1, 1, 1, 1, 1, 1, 1]" in r.stdout, r.stdout + r.stderr[-1500:]
