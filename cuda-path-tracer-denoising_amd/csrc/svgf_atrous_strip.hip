@@ -53,11 +53,13 @@ constexpr float kLog2e = 1.44269504088896340736f;
 // With SVGF_PROGRESS_PRIO a compute wave starts every iteration at priority 3 and lowers itself as it completes tap
 // rows: whichever wave is behind outranks the one that is ahead, both finish together, and the iteration shrinks from
 // ~7250 to ~6300 cycles (profiles/r01_exp_progress_prio.log).  Loader waves sit at SVGF_LOADER_PRIO.
+// Round 6 (A/B harness, 2048x1152, profiles/r06_ab_lane_prio.txt): 3 held through the first TWO tap rows, then 2, then 1 (was 3, 2, 1, 0),
+// loaders at 1 (was 2): 51.0 -> 50.2 us per level, as the lane kernel's schedule of the same round.
 #ifndef SVGF_PROGRESS_PRIO
 #define SVGF_PROGRESS_PRIO 1
 #endif
 #ifndef SVGF_LOADER_PRIO
-#define SVGF_LOADER_PRIO 2
+#define SVGF_LOADER_PRIO 1
 #endif
 // ROWS <= 2: SVGF_LOADER_GROUPS groups of TX / SVGF_LOADER_DIV threads take turns (issue / in flight / commit).
 // ROWS == 3: 12 compute waves leave room for 4 loader waves (1024 threads): one group of TX threads that commits and
@@ -609,9 +611,9 @@ __global__ __launch_bounds__(TX * ROWS + loader_threads(TX, ROWS)) void k_atrous
                     }
                     // the wave that is ahead lowers its own priority, so the two compute waves of a SIMD finish together
 #if SVGF_PROGRESS_PRIO
-                    if (j == -1) __builtin_amdgcn_s_setprio(2);
-                    if (j == 0) __builtin_amdgcn_s_setprio(1);
-                    if (j == 1) __builtin_amdgcn_s_setprio(0);
+                    if (j == -1) __builtin_amdgcn_s_setprio(3);
+                    if (j == 0) __builtin_amdgcn_s_setprio(2);
+                    if (j == 1) __builtin_amdgcn_s_setprio(1);
 #endif
                 }
             } else {
